@@ -1,0 +1,615 @@
+// rt_api.hip - C ABI of libgpurt.so (declared in include/gpurt.h) and the launch logic.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+//        -fno-gpu-flush-denormals-to-zero -shared -fPIC
+#pragma clang fp contract(off)
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gpurt.h"
+#include "rt_kernels.h"
+#include "rt_pipeline.h"
+
+using namespace rt;
+
+struct rt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    // scene
+    float4 *d_geo = nullptr, *d_shade = nullptr, *d_mats = nullptr;
+    int *d_has_tex = nullptr;
+    uint32_t **d_atlas_ptrs = nullptr;
+    std::vector<uint32_t *> atlas_layers;
+    float4 *d_env = nullptr;
+    int env_w = 0, env_h = 0;
+    int count = 0, lights = 0, n_mat = 0, atlas_size = 4096;
+    bool have_scene = false;
+
+    // target
+    uint32_t width = 0, height = 0;
+    float4 *d_sum_own = nullptr, *d_sum = nullptr;
+    uint64_t n_samples = 0;
+
+    // frame
+    DFrame frame;
+    bool have_frame = false;
+
+    // per-launch sample tables
+    uint32_t *d_samples = nullptr, *d_light_seeds = nullptr;
+    uint32_t sample_cap = 0;
+    uint32_t chain_pos = 0, chain_val = 0;   // light-seed chain: chain_val = hash^chain_pos(clock)
+    bool chain_valid = false;
+
+    // options
+    int pipeline = 1;
+    int batch_samples = 4;
+    int profiling = 0;
+
+    // stats
+    DStats *d_stats = nullptr;
+    rt_stats host_stats;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    Pipeline pipe;
+};
+
+namespace {
+
+int fail(rt_context *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                    \
+    } while (0)
+
+int bind_device(rt_context *ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+DScene device_scene(const rt_context *ctx) {
+    DScene sc;
+    sc.geo = ctx->d_geo;
+    sc.shade = ctx->d_shade;
+    sc.mats = ctx->d_mats;
+    sc.has_tex = ctx->d_has_tex;
+    sc.atlas = ctx->d_atlas_ptrs;
+    sc.env = ctx->d_env;
+    sc.count = ctx->count;
+    sc.lights = ctx->lights;
+    sc.n_mat = ctx->n_mat;
+    sc.atlas_size = ctx->atlas_size;
+    sc.atlas_layers = (int)ctx->atlas_layers.size();
+    sc.env_w = ctx->env_w;
+    sc.env_h = ctx->env_h;
+    return sc;
+}
+
+uint32_t pcg_hash_host(uint32_t k) {
+    const uint32_t state = k * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+// light_seed of a sample = CLOCK hashed SAMPLE times (raytracer.glsl:595-598); the chain is
+// continued from the last position when samples ascend.
+uint32_t light_seed_for(rt_context *ctx, uint32_t sample) {
+    if (!ctx->chain_valid || sample < ctx->chain_pos) {
+        ctx->chain_pos = 0;
+        ctx->chain_val = ctx->frame.clock;
+        ctx->chain_valid = true;
+    }
+    while (ctx->chain_pos < sample) {
+        ctx->chain_val = pcg_hash_host(ctx->chain_val);
+        ctx->chain_pos++;
+    }
+    return ctx->chain_val;
+}
+
+void free_atlas(rt_context *ctx) {
+    for (uint32_t *p : ctx->atlas_layers)
+        if (p) (void)hipFree(p);
+    ctx->atlas_layers.clear();
+    if (ctx->d_atlas_ptrs) (void)hipFree(ctx->d_atlas_ptrs);
+    ctx->d_atlas_ptrs = nullptr;
+}
+
+void free_scene(rt_context *ctx) {
+    if (ctx->d_geo) (void)hipFree(ctx->d_geo);
+    if (ctx->d_shade) (void)hipFree(ctx->d_shade);
+    if (ctx->d_mats) (void)hipFree(ctx->d_mats);
+    if (ctx->d_has_tex) (void)hipFree(ctx->d_has_tex);
+    ctx->d_geo = ctx->d_shade = ctx->d_mats = nullptr;
+    ctx->d_has_tex = nullptr;
+    free_atlas(ctx);
+    ctx->have_scene = false;
+}
+
+// RGBA32F -> packed R11F_G11F_B10F.  Negative -> 0, NaN -> NaN, +Inf -> Inf, above the largest finite
+// value -> the largest finite value, otherwise round to nearest even (denormals kept).
+__device__ uint32_t encode_ufloat(float f, int mbits) {
+    const uint32_t bits = __float_as_uint(f);
+    const uint32_t neg = bits >> 31, ex = (bits >> 23) & 0xFFu, man = bits & 0x7FFFFFu;
+    const uint32_t top = (30u << mbits) | ((1u << mbits) - 1u);
+    if (ex == 255u) return man ? ((31u << mbits) | 1u) : (neg ? 0u : (31u << mbits));
+    if (neg) return 0u;
+    const int e = (int)ex - 112;                 // target biased exponent
+    if (e >= 31) return top;
+    uint32_t code;
+    if (e <= 0) {
+        code = (uint32_t)__float2int_rn(f * (float)(1u << (14 + mbits)));
+    } else {
+        const int sh = 23 - mbits;
+        const uint32_t keep = man >> sh, rest = man & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        code = ((uint32_t)e << mbits) + keep + ((rest > half || (rest == half && (keep & 1u))) ? 1u : 0u);
+    }
+    return code > top ? top : code;
+}
+
+__global__ void k_pack_atlas(const float4 *__restrict__ src, uint32_t w, uint32_t h, uint32_t *__restrict__ dst,
+                             uint32_t size) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const float4 p = src[(size_t)y * w + x];
+    dst[(size_t)y * size + x] = encode_ufloat(p.x, 6) | (encode_ufloat(p.y, 6) << 11) | (encode_ufloat(p.z, 5) << 22);
+}
+
+__global__ void k_sum_to_rgb(const float4 *__restrict__ sum, unsigned long long n, float *__restrict__ rgb) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 s = sum[i];
+    rgb[i * 3 + 0] = s.x;
+    rgb[i * 3 + 1] = s.y;
+    rgb[i * 3 + 2] = s.z;
+}
+
+int ensure_sample_tables(rt_context *ctx, uint32_t n) {
+    if (n <= ctx->sample_cap) return RT_OK;
+    if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+    if (ctx->d_light_seeds) (void)hipFree(ctx->d_light_seeds);
+    ctx->d_samples = ctx->d_light_seeds = nullptr;
+    ctx->sample_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_samples, sizeof(uint32_t) * n));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_light_seeds, sizeof(uint32_t) * n));
+    ctx->sample_cap = n;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(int device, rt_context **out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RT_ERR_DEVICE;
+    rt_context *ctx = new (std::nothrow) rt_context();
+    if (!ctx) return RT_ERR_NOMEM;
+    ctx->device = device;
+    memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
+    memset(&ctx->frame, 0, sizeof(ctx->frame));
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess ||
+        hipMalloc(&ctx->d_stats, sizeof(DStats)) != hipSuccess ||
+        hipMemset(ctx->d_stats, 0, sizeof(DStats)) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+        hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_DEVICE;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_destroy(rt_context *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    ctx->pipe.release();
+    if (ctx->d_env) (void)hipFree(ctx->d_env);
+    if (ctx->d_sum_own) (void)hipFree(ctx->d_sum_own);
+    if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+    if (ctx->d_light_seeds) (void)hipFree(ctx->d_light_seeds);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return RT_OK;
+}
+
+const char *rt_last_error(const rt_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rt_set_stream(rt_context *ctx, void *hip_stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RT_OK;
+}
+
+int rt_synchronize(rt_context *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_upload_scene(rt_context *ctx, const rt_triangle_model *models, const rt_triangle_shading *shadings,
+                    uint32_t count, uint32_t lights, const rt_material *materials, uint32_t n_materials) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (count == 0 || !models || !shadings || !materials || n_materials == 0)
+        return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: empty scene");
+    if (lights > count) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: lights (%u) > count (%u)", lights, count);
+    if (count > 0x3FFFFFFFu) return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: more than 2^30 triangles");
+    for (uint32_t i = 0; i < count; i++)
+        if (shadings[i].material_id >= n_materials)
+            return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: triangle %u names material %u of %u", i,
+                        shadings[i].material_id, n_materials);
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+
+    // geometry: the 48-byte record as is (3 x float4); shading: 7 float4 planes
+    std::vector<float4> shade((size_t)7 * count);
+    for (uint32_t i = 0; i < count; i++) {
+        const rt_triangle_shading &s = shadings[i];
+        float idbits;
+        memcpy(&idbits, &s.material_id, 4);
+        shade[(size_t)0 * count + i] = make_float4(s.normals[0][0], s.normals[0][1], s.normals[0][2], idbits);
+        shade[(size_t)1 * count + i] = make_float4(s.normals[1][0], s.normals[1][1], s.normals[1][2], s.tex_p[0]);
+        shade[(size_t)2 * count + i] = make_float4(s.normals[2][0], s.normals[2][1], s.normals[2][2], s.tex_p[1]);
+        shade[(size_t)3 * count + i] = make_float4(s.tex_u[0], s.tex_u[1], s.tex_v[0], s.tex_v[1]);
+        for (int k = 0; k < 3; k++)
+            shade[(size_t)(4 + k) * count + i] = make_float4(s.tangents[k][0], s.tangents[k][1], s.tangents[k][2], 0.0f);
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->d_geo, sizeof(rt_triangle_model) * (size_t)count));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_shade, sizeof(float4) * shade.size()));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_mats, sizeof(rt_material) * (size_t)n_materials));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_has_tex, sizeof(int) * (size_t)n_materials));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_geo, models, sizeof(rt_triangle_model) * (size_t)count, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_shade, shade.data(), sizeof(float4) * shade.size(), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_mats, materials, sizeof(rt_material) * (size_t)n_materials, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ctx->d_has_tex, 0, sizeof(int) * (size_t)n_materials));
+    ctx->atlas_layers.assign((size_t)n_materials * 3, nullptr);
+    HIP_TRY(ctx, hipMalloc(&ctx->d_atlas_ptrs, sizeof(uint32_t *) * ctx->atlas_layers.size()));
+    HIP_TRY(ctx, hipMemset(ctx->d_atlas_ptrs, 0, sizeof(uint32_t *) * ctx->atlas_layers.size()));
+    ctx->count = (int)count;
+    ctx->lights = (int)lights;
+    ctx->n_mat = (int)n_materials;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+int rt_set_atlas_size(rt_context *ctx, uint32_t size) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (size == 0 || size > 16384) return fail(ctx, RT_ERR_LIMIT, "rt_set_atlas_size: size %u not in [1, 16384]", size);
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t *&p : ctx->atlas_layers) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    if (ctx->d_atlas_ptrs)
+        HIP_TRY(ctx, hipMemset(ctx->d_atlas_ptrs, 0, sizeof(uint32_t *) * ctx->atlas_layers.size()));
+    ctx->atlas_size = (int)size;
+    return RT_OK;
+}
+
+int rt_upload_atlas_layer(rt_context *ctx, uint32_t material, uint32_t slot, uint32_t w, uint32_t h,
+                          const float *rgba) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "rt_upload_atlas_layer: no scene");
+    if (material >= (uint32_t)ctx->n_mat || slot > 2 || !rgba || w == 0 || h == 0)
+        return fail(ctx, RT_ERR_INVALID, "rt_upload_atlas_layer: bad material/slot/pixels");
+    if (w > (uint32_t)ctx->atlas_size || h > (uint32_t)ctx->atlas_size)
+        return fail(ctx, RT_ERR_LIMIT, "rt_upload_atlas_layer: %ux%u exceeds the %d-texel atlas", w, h, ctx->atlas_size);
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    const size_t layer = (size_t)material * 3 + slot;
+    const size_t texels = (size_t)ctx->atlas_size * ctx->atlas_size;
+    if (!ctx->atlas_layers[layer]) HIP_TRY(ctx, hipMalloc(&ctx->atlas_layers[layer], texels * sizeof(uint32_t)));
+    uint32_t *dst = ctx->atlas_layers[layer];
+    float4 *staging = nullptr;
+    HIP_TRY(ctx, hipMalloc(&staging, sizeof(float4) * (size_t)w * h));
+    hipError_t e = hipMemcpyAsync(staging, rgba, sizeof(float4) * (size_t)w * h, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dst, 0, texels * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) {
+        dim3 grid((w + 255) / 256, h);
+        hipLaunchKernelGGL(k_pack_atlas, grid, dim3(256), 0, ctx->stream, staging, w, h, dst, (uint32_t)ctx->atlas_size);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(ctx->d_atlas_ptrs + layer, &ctx->atlas_layers[layer], sizeof(uint32_t *),
+                           hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(staging);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "rt_upload_atlas_layer: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_set_has_texture(rt_context *ctx, const int32_t *flags, uint32_t n) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "rt_set_has_texture: no scene");
+    if (!flags || n > (uint32_t)ctx->n_mat) return fail(ctx, RT_ERR_INVALID, "rt_set_has_texture: bad flags");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_has_tex, flags, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_upload_env(rt_context *ctx, uint32_t w, uint32_t h, const float *rgba) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!rgba || w == 0 || h == 0 || w > 65536 || h > 65536) return fail(ctx, RT_ERR_INVALID, "rt_upload_env: bad image");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_env) (void)hipFree(ctx->d_env);
+    ctx->d_env = nullptr;
+    ctx->env_w = ctx->env_h = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_env, sizeof(float4) * (size_t)w * h));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_env, rgba, sizeof(float4) * (size_t)w * h, hipMemcpyHostToDevice));
+    ctx->env_w = (int)w;
+    ctx->env_h = (int)h;
+    return RT_OK;
+}
+
+int rt_resize(rt_context *ctx, uint32_t width, uint32_t height) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768)
+        return fail(ctx, RT_ERR_LIMIT, "rt_resize: %ux%u not in [1, 32768]^2", width, height);
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const bool external = ctx->d_sum && ctx->d_sum != ctx->d_sum_own;
+    if (external && (width != ctx->width || height != ctx->height)) {
+        ctx->d_sum = nullptr;   // a caller-owned buffer of the old size cannot be kept
+    }
+    if (!external || !ctx->d_sum) {
+        if (ctx->d_sum_own) (void)hipFree(ctx->d_sum_own);
+        ctx->d_sum_own = nullptr;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_sum_own, sizeof(float4) * (size_t)width * height));
+        ctx->d_sum = ctx->d_sum_own;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_sum, 0, sizeof(float4) * (size_t)width * height, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(DStats), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->width = width;
+    ctx->height = height;
+    ctx->n_samples = 0;
+    memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
+    return RT_OK;
+}
+
+int rt_set_sum_buffer(rt_context *ctx, float *device_rgba) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (ctx->width == 0) return fail(ctx, RT_ERR_STATE, "rt_set_sum_buffer: call rt_resize first");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (device_rgba) {
+        ctx->d_sum = (float4 *)device_rgba;
+    } else {
+        if (!ctx->d_sum_own)
+            HIP_TRY(ctx, hipMalloc(&ctx->d_sum_own, sizeof(float4) * (size_t)ctx->width * ctx->height));
+        ctx->d_sum = ctx->d_sum_own;
+    }
+    return RT_OK;
+}
+
+int rt_set_frame(rt_context *ctx, const float camera[16], uint32_t clock, int32_t recursion, float exposure) {
+    if (!ctx || !camera) return RT_ERR_INVALID;
+    if (recursion > 4096) return fail(ctx, RT_ERR_LIMIT, "rt_set_frame: recursion %d > 4096", recursion);
+    memcpy(ctx->frame.cam, camera, sizeof(float) * 16);
+    ctx->frame.clock = clock;
+    ctx->frame.recursion = recursion;
+    ctx->frame.exposure = exposure;
+    ctx->have_frame = true;
+    ctx->chain_valid = false;
+    return RT_OK;
+}
+
+int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint32_t sample_stride) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "rt_trace: no scene uploaded");
+    if (!ctx->have_frame) return fail(ctx, RT_ERR_STATE, "rt_trace: no frame set");
+    if (ctx->width == 0 || !ctx->d_sum) return fail(ctx, RT_ERR_STATE, "rt_trace: no target (rt_resize)");
+    if (sample_count == 0) return RT_OK;
+    if (sample_stride == 0) return fail(ctx, RT_ERR_INVALID, "rt_trace: sample_stride 0");
+    if ((uint64_t)sample_begin + (uint64_t)(sample_count - 1) * sample_stride > 0xFFFFFFFEull)
+        return fail(ctx, RT_ERR_LIMIT, "rt_trace: sample index beyond 2^32 - 2");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+
+    ctx->frame.width = ctx->width;
+    ctx->frame.height = ctx->height;
+    const DScene sc = device_scene(ctx);
+
+    // samples are processed in chunks so that the per-launch tables stay small
+    const uint32_t chunk_max = ctx->pipeline == 0 ? 1024u : (uint32_t)(ctx->batch_samples > 0 ? ctx->batch_samples : 1);
+    int rc = ensure_sample_tables(ctx, chunk_max);
+    if (rc) return rc;
+    std::vector<uint32_t> samples(chunk_max), seeds(chunk_max);
+
+    for (uint32_t done = 0; done < sample_count;) {
+        const uint32_t n = (sample_count - done < chunk_max) ? sample_count - done : chunk_max;
+        for (uint32_t k = 0; k < n; k++) {
+            samples[k] = sample_begin + (done + k) * sample_stride;
+            seeds[k] = light_seed_for(ctx, samples[k]);
+        }
+        // the tables of the previous chunk may still be in use by queued kernels
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_samples, samples.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_light_seeds, seeds.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if (ctx->pipeline == 0) {
+            const uint32_t tiles = ((ctx->width + 7u) >> 3) * ((ctx->height + 7u) >> 3);
+            hipLaunchKernelGGL(k_trace_mega, dim3(tiles), dim3(64), 0, ctx->stream, sc, ctx->frame, ctx->d_sum,
+                               ctx->d_samples, ctx->d_light_seeds, (int)n, ctx->d_stats);
+            HIP_TRY(ctx, hipGetLastError());
+        } else {
+            const char *msg = nullptr;
+            ctx->pipe.h_light_seeds.assign(seeds.begin(), seeds.begin() + n);
+            hipError_t e = ctx->pipe.run(sc, ctx->frame, ctx->d_sum, ctx->d_samples, ctx->d_light_seeds, (int)n,
+                                         ctx->d_stats, ctx->stream, ctx->profiling != 0, &ctx->host_stats, &msg);
+            if (e != hipSuccess)
+                return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
+                            msg ? msg : "pipeline", hipGetErrorString(e));
+        }
+        if (ctx->profiling) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+            float ms = 0.0f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            ctx->host_stats.trace_ms += (double)ms;
+        }
+        done += n;
+    }
+    ctx->n_samples += sample_count;
+    return RT_OK;
+}
+
+int rt_read_sum(rt_context *ctx, float *rgb, uint64_t *n_samples) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (ctx->width == 0 || !ctx->d_sum) return fail(ctx, RT_ERR_STATE, "rt_read_sum: no target");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    const unsigned long long n = (unsigned long long)ctx->width * ctx->height;
+    if (rgb) {
+        float *d_rgb = nullptr;
+        HIP_TRY(ctx, hipMalloc(&d_rgb, sizeof(float) * 3 * n));
+        hipLaunchKernelGGL(k_sum_to_rgb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_sum, n, d_rgb);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_rgb, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_rgb);
+        if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "rt_read_sum: %s", hipGetErrorString(e));
+    } else {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n_samples) *n_samples = ctx->n_samples;
+    return RT_OK;
+}
+
+int rt_read_srgb8(rt_context *ctx, uint8_t *rgb) {
+    if (!ctx || !rgb) return RT_ERR_INVALID;
+    if (ctx->width == 0 || !ctx->d_sum) return fail(ctx, RT_ERR_STATE, "rt_read_srgb8: no target");
+    if (ctx->n_samples == 0) return fail(ctx, RT_ERR_STATE, "rt_read_srgb8: nothing rendered yet");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    const unsigned long long n = (unsigned long long)ctx->width * ctx->height;
+    unsigned char *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_out, 3 * n));
+    hipLaunchKernelGGL(k_srgb8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_sum,
+                       1.0f / (float)ctx->n_samples, n, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_out, 3 * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "rt_read_srgb8: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_closest_hit_batch_device(rt_context *ctx, const float *o_xyz, const float *d_xyz, uint64_t n, int32_t *id,
+                                float *uvt) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "rt_closest_hit_batch: no scene uploaded");
+    if (n == 0) return RT_OK;
+    if (!o_xyz || !d_xyz || !id || !uvt) return fail(ctx, RT_ERR_INVALID, "rt_closest_hit_batch: null array");
+    if (n > (1ull << 31)) return fail(ctx, RT_ERR_LIMIT, "rt_closest_hit_batch: more than 2^31 rays");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    const DScene sc = device_scene(ctx);
+    hipLaunchKernelGGL(k_closest_hit_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc, o_xyz,
+                       d_xyz, (unsigned long long)n, id, uvt);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_closest_hit_batch(rt_context *ctx, const float *o_xyz, const float *d_xyz, uint64_t n, int32_t *id,
+                         float *uvt) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RT_ERR_STATE, "rt_closest_hit_batch: no scene uploaded");
+    if (n == 0) return RT_OK;
+    if (!o_xyz || !d_xyz || !id || !uvt) return fail(ctx, RT_ERR_INVALID, "rt_closest_hit_batch: null array");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    float *d_o = nullptr, *d_d = nullptr, *d_uvt = nullptr;
+    int32_t *d_id = nullptr;
+    int rc = RT_OK;
+    hipError_t e = hipMalloc(&d_o, sizeof(float) * 3 * n);
+    if (e == hipSuccess) e = hipMalloc(&d_d, sizeof(float) * 3 * n);
+    if (e == hipSuccess) e = hipMalloc(&d_uvt, sizeof(float) * 3 * n);
+    if (e == hipSuccess) e = hipMalloc(&d_id, sizeof(int32_t) * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_o, o_xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d, d_xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        rc = rt_closest_hit_batch_device(ctx, d_o, d_d, n, d_id, d_uvt);
+        if (rc == RT_OK) {
+            e = hipMemcpyAsync(id, d_id, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(uvt, d_uvt, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+    }
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_uvt); (void)hipFree(d_id);
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE,
+                                     "rt_closest_hit_batch: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_context *ctx, rt_stats *out) {
+    if (!ctx || !out) return RT_ERR_INVALID;
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DStats ds;
+    HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
+    rt_stats s = ctx->host_stats;
+    s.pixel_samples = ds.pixel_samples;
+    s.rays = ds.rays;
+    s.shadow_probes = ds.shadow_probes;
+    s.glossy_probes = ds.glossy_probes;
+    s.closest_tests = ds.rays * (uint64_t)ctx->count;
+    s.probe_tests = (ds.shadow_probes + ds.glossy_probes) * (uint64_t)(ctx->count > 0 ? ctx->count - 1 : 0);
+    *out = s;
+    return RT_OK;
+}
+
+int rt_reset_stats(rt_context *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemset(ctx->d_stats, 0, sizeof(DStats)));
+    memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
+    return RT_OK;
+}
+
+int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return RT_ERR_INVALID;
+    if (!strcmp(name, "pipeline")) {
+        if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "pipeline must be 0 or 1");
+        ctx->pipeline = (int)value;
+    } else if (!strcmp(name, "batch_samples")) {
+        if (value < 1 || value > 64) return fail(ctx, RT_ERR_LIMIT, "batch_samples must be in [1, 64]");
+        ctx->batch_samples = (int)value;
+    } else if (!strcmp(name, "profiling")) {
+        ctx->profiling = value ? 1 : 0;
+    } else {
+        return fail(ctx, RT_ERR_INVALID, "unknown option %s", name);
+    }
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+// rt_kernels.h - gfx950 kernels of the path tracer (included once, by rt_api.hip).
+//
+// Mapping: one lane = one ray/path, one wave64 = 64 rays.  In the brute-force loops the
+// triangle index is the same in every lane, so triangle records are read with scalar
+// loads into SGPRs and the vector ALU only runs the intersection arithmetic.
+#pragma once
+
+#include "rt_device.h"
+
+namespace rt {
+
+// Device-side work counters (see rt_stats in gpurt.h).
+struct DStats {
+    unsigned long long pixel_samples, rays, shadow_probes, glossy_probes;
+};
+
+RT_DEV unsigned long long wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return (unsigned long long)v;
+}
+
+// ---------------------------------------------------------------- brute-force loops
+
+// findIntersection, raytracer.glsl:217-235.  Returns the triangle id (-1 = miss); isec as left
+// by the fold (x, y, relative_depth, determinant).
+RT_DEV int closest_hit_bf(const DScene &sc, const Ray &ray, f4 &isec) {
+    int best = -1;
+    isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 1.0f;
+    const float4 *__restrict__ geo = sc.geo;
+    const int count = sc.count;
+    for (int i = 0; i < count; i++) {
+        const Tri t = load_tri(geo, i);
+        if (intersect_triangle(ray, t, isec)) best = i;
+    }
+    return best;
+}
+
+// Occlusion loop of sampleLight, raytracer.glsl:372-378.  `active` lanes run the loop; returns
+// true for lanes whose probe ray is blocked.  The loop ends as soon as no lane needs it.
+RT_DEV bool shadow_any_hit_bf(const DScene &sc, const Ray &ray, float max_t, int current, bool active) {
+    bool blocked = false;
+    const float4 *__restrict__ geo = sc.geo;
+    const int count = sc.count;
+    for (int i = 0; i < count; i++) {
+        if (__builtin_amdgcn_ballot_w64(active && !blocked) == 0ull) break;
+        const Tri t = load_tri(geo, i);
+        const bool h = intersect_triangle_shadow(ray, t, max_t);
+        if (active && h && (i != current)) blocked = true;
+    }
+    return blocked;
+}
+
+// Search loop of sampleLightGlossy, raytracer.glsl:403-419, in its two-phase form: triangles
+// [0, lights) fold to the closest light hit; any triangle of [lights, count) that passes the test
+// against that state ends the search as "occluded".  Outcome: 0 occluded, 1 nothing hit,
+// 2 light `light_id` visible with `isec`.
+RT_DEV int glossy_search_bf(const DScene &sc, const Ray &ray, int current, bool active, int &light_id, f4 &isec) {
+    isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
+    light_id = -1;
+    const float4 *__restrict__ geo = sc.geo;
+    const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
+    for (int i = 0; i < lights; i++) {
+        const Tri t = load_tri(geo, i);
+        f4 trial = isec;
+        const bool h = intersect_triangle(ray, t, trial);
+        if (active && h && (i != current)) { isec = trial; light_id = i; }
+    }
+    bool blocked = false;
+    for (int i = lights; i < count; i++) {
+        if (__builtin_amdgcn_ballot_w64(active && !blocked) == 0ull) break;
+        const Tri t = load_tri(geo, i);
+        f4 trial = isec;
+        const bool h = intersect_triangle(ray, t, trial);
+        if (active && h && (i != current)) blocked = true;
+    }
+    if (blocked) return 0;
+    return light_id < 0 ? 1 : 2;
+}
+
+// ---------------------------------------------------------------- single-kernel path tracer
+//
+// One wave per 8x8 pixel tile (the reference's workgroup shape, raytracer.glsl:3), one lane per
+// pixel; a lane walks its whole path.  Simple and exact, but lanes whose path has ended idle until
+// the longest path of the wave is done; the staged pipeline below removes that.
+__global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 *__restrict__ sum,
+                                                   const uint32_t *__restrict__ samples,
+                                                   const uint32_t *__restrict__ light_seeds, int n_samples,
+                                                   DStats *__restrict__ stats) {
+    const uint32_t tiles_x = (fr.width + 7u) >> 3;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
+    const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
+    const bool in_image = (tx < fr.width) && (ty < fr.height);
+
+    uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0, n_paths = 0;
+    f3 acc = mk3(0.0f, 0.0f, 0.0f);
+    const size_t pix = (size_t)ty * fr.width + tx;
+    if (in_image) {
+        const float4 s = sum[pix];
+        acc = mk3(s.x, s.y, s.z);
+    }
+    const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
+
+    for (int k = 0; k < n_samples; k++) {
+        const uint32_t sample = samples[k];
+        uint32_t light_seed = light_seeds[k];
+        PathState ps;
+        ps.seed = pixel_seed(fr, tx, ty, sample);
+        const Ray cam = camera_ray(fr, tx, ty, ps.seed);
+        ps.o = cam.o; ps.d = cam.d;
+        ps.path = mk3(1.0f, 1.0f, 1.0f);
+        ps.energy = mk3(0.0f, 0.0f, 0.0f);
+        bool alive = in_image;
+        n_paths += alive ? 1u : 0u;
+
+        for (int depth = 0; depth < max_depth; depth++) {
+            if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+            const bool coin_diffuse = unit_float(light_seed) < 0.5f;       // :553, same for every pixel
+            Ray ray; ray.o = ps.o; ray.d = ps.d;
+            f4 isec;
+            const int hit = closest_hit_bf(sc, ray, isec);
+            n_rays += alive ? 1u : 0u;
+
+            Bounce bn;
+            bn.kind = PROBE_NONE; bn.current = 0; bn.max_t = 0.0f; bn.w = 0.0f;
+            bn.c = mk3(0.0f, 0.0f, 0.0f); bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
+            bool shaded = false;
+            if (alive) {
+                if (hit < 0) {
+                    ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;     // :452-456
+                    alive = false;
+                } else {
+                    const float inv_det = 1.0f / isec.w;
+                    shade_pre(sc, fr, ps, hit, isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, coin_diffuse, bn);
+                    shaded = true;
+                }
+            }
+            Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
+            bool has_light = false;
+            f3 global_light = mk3(0.0f, 0.0f, 0.0f);
+            if (coin_diffuse) {
+                const bool run = shaded && bn.kind == PROBE_SHADOW;
+                if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+                    const bool blocked = shadow_any_hit_bf(sc, probe, bn.max_t, bn.current, run);
+                    n_shadow += run ? 1u : 0u;
+                    if (run && !blocked) { has_light = true; global_light = bn.c; }
+                }
+            } else {
+                const bool run = shaded && bn.kind == PROBE_GLOSSY;
+                if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+                    int light_id; f4 lsec;
+                    const int outcome = glossy_search_bf(sc, probe, bn.current, run, light_id, lsec);
+                    n_glossy += run ? 1u : 0u;
+                    if (run && outcome != 0) {
+                        has_light = true;
+                        global_light = glossy_global_light(bn, glossy_light(sc, fr, bn.probe_d, outcome == 2 ? light_id : -1, lsec));
+                    }
+                }
+            }
+            if (shaded) alive = shade_post(sc, ps, bn.current, has_light, global_light);
+        }
+        acc = acc + ps.energy;
+    }
+    if (in_image) sum[pix] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+
+    const unsigned long long r = wave_sum_u32(n_rays), s = wave_sum_u32(n_shadow), g = wave_sum_u32(n_glossy),
+                             p = wave_sum_u32(n_paths);
+    if (lane == 0) {
+        atomicAdd(&stats->rays, r);
+        atomicAdd(&stats->shadow_probes, s);
+        atomicAdd(&stats->glossy_probes, g);
+        atomicAdd(&stats->pixel_samples, p);
+    }
+}
+
+// ---------------------------------------------------------------- closest hit for a ray batch
+
+__global__ __launch_bounds__(256) void k_closest_hit_batch(DScene sc, const float *__restrict__ o,
+                                                           const float *__restrict__ d, unsigned long long n,
+                                                           int *__restrict__ id, float *__restrict__ uvt) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const unsigned long long j = live ? i : 0ull;
+    Ray ray;
+    ray.o = mk3(o[j * 3 + 0], o[j * 3 + 1], o[j * 3 + 2]);
+    ray.d = mk3(d[j * 3 + 0], d[j * 3 + 1], d[j * 3 + 2]);
+    f4 isec;
+    const int hit = closest_hit_bf(sc, ray, isec);
+    if (live) {
+        const float inv_det = 1.0f / isec.w;
+        id[i] = hit;
+        uvt[i * 3 + 0] = isec.x * inv_det;
+        uvt[i * 3 + 1] = isec.y * inv_det;
+        uvt[i * 3 + 2] = isec.z * inv_det;
+    }
+}
+
+// sRGB transfer of the mean image, displayQuad.fs:19-34.
+__global__ void k_srgb8(const float4 *__restrict__ sum, float inv_n, unsigned long long n_pixels,
+                        unsigned char *__restrict__ out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    const float4 s = sum[i];
+    const float c[3] = {s.x * inv_n, s.y * inv_n, s.z * inv_n};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float v = (c[k] <= 0.0031308f) ? c[k] * 12.92f : 1.055f * __powf(c[k], 1.0f / 2.4f) - 0.055f;
+        v = v * 255.0f + 0.5f;
+        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        out[i * 3 + k] = (unsigned char)v;
+    }
+}
+
+}  // namespace rt

@@ -1,0 +1,414 @@
+// rt_pipeline.h - staged ("wavefront") form of the path tracer for gfx950.
+//
+// The reference walks a whole path in one shader invocation (raytracer.glsl:440-584).  Paths
+// of one wave end at different depths and only some of them need a probe loop, so a wave that
+// keeps its 64 pixels for the whole walk soon runs mostly idle lanes through the O(COUNT)
+// loops.  Here a bounce is split into stages that each run as their own kernel over a densely
+// packed queue of path ids:
+//
+//   extend   closest hit (findIntersection) + everything of the bounce up to the probe loop;
+//            paths that need a probe are appended to the shadow or the glossy queue, paths that
+//            need none are finished (roulette) and appended to the next extend queue
+//   shadow   occlusion loop of sampleLight + rest of the bounce        -> next extend queue
+//   glossy   search loop of sampleLightGlossy + rest of the bounce     -> next extend queue
+//   resolve  adds the radiance of the batch's paths to the per-pixel sums in ascending sample order
+//
+// Queues are filled with one atomic per wave (ballot + mbcnt compaction).  The order of ids in a
+// queue varies from run to run, but a path's arithmetic depends on its own state only and the
+// resolve stage adds in a fixed order, so results are reproducible bit for bit.
+//
+// Path state lives in HBM as structure-of-arrays float4 planes indexed by path id:
+//   s0 = (o.xyz, d.x)  s1 = (d.yz, path.xy)  s2 = (path.z, energy.xyz)
+//   s3 = (seed, current triangle)            written by extend, read by the probe stages
+//   p0 = (probe_d.xyz, max_t)  p1 = (c.xyz, w)   (see struct Bounce)
+// Path id = slot * paths_per_sample + tile * 64 + lane, where `slot` is the sample's position in
+// the batch and (tile, lane) is the 8x8 pixel tile and the pixel inside it, so that the depth-0
+// wave holds the same 64 pixels as a reference workgroup.
+#pragma once
+
+#include <vector>
+
+#include "../../include/gpurt.h"
+#include "rt_kernels.h"
+
+namespace rt {
+
+struct PipeBuffers {
+    float4 *s0, *s1, *s2, *p0, *p1;
+    uint2 *s3;
+    uint32_t *q_ext[2];
+    uint32_t *q_shadow, *q_glossy;
+    uint32_t *counters;   // [depth][4]: 0 extend count, 1 shadow count, 2 glossy count, 3 unused
+};
+
+constexpr int PIPE_WAVES = 256 * 16;    // persistent grid: 16 single-wave workgroups per CU
+
+RT_DEV void load_path(const PipeBuffers &b, uint32_t id, PathState &ps) {
+    const float4 a = b.s0[id], c = b.s1[id], e = b.s2[id];
+    ps.o = mk3(a.x, a.y, a.z);
+    ps.d = mk3(a.w, c.x, c.y);
+    ps.path = mk3(c.z, c.w, e.x);
+    ps.energy = mk3(e.y, e.z, e.w);
+}
+RT_DEV void store_path(const PipeBuffers &b, uint32_t id, const PathState &ps) {
+    b.s0[id] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+    b.s1[id] = make_float4(ps.d.y, ps.d.z, ps.path.x, ps.path.y);
+    b.s2[id] = make_float4(ps.path.z, ps.energy.x, ps.energy.y, ps.energy.z);
+}
+
+// Appends `id` of every lane with `pred` to a queue: one atomic per wave.
+RT_DEV void queue_push(uint32_t *__restrict__ queue, uint32_t *__restrict__ counter, bool pred, uint32_t id) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(pred);
+    if (mask == 0ull) return;
+    const uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (lane_rank == 0 && pred) base = atomicAdd(counter, total);
+    // the lane that did the atomic is the lowest set bit of mask
+    const int leader = __ffsll((long long)mask) - 1;
+    base = __shfl(base, leader, 64);
+    if (pred) queue[base + lane_rank] = id;
+}
+
+// Extend stage.  FIRST: depth 0, the wave generates the camera rays of its 64 pixels itself
+// (raytracer.glsl:586-607) instead of reading a queue.
+template <bool FIRST>
+__global__ __launch_bounds__(64) void k_extend(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
+                                               const uint32_t *__restrict__ samples,
+                                               const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
+                                               uint32_t n_slots, int max_depth, DStats *__restrict__ stats) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t *cnt = b.counters + 4 * depth;
+    uint32_t *cnt_next = b.counters + 4 * (depth + 1);
+    const uint32_t total = FIRST ? paths_per_sample * n_slots : cnt[0];
+    const uint32_t *__restrict__ q = b.q_ext[q_in];
+    uint32_t *q_next = b.q_ext[q_in ^ 1];
+    const uint32_t tiles_x = (fr.width + 7u) >> 3;
+    uint32_t n_paths = 0;
+
+    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+        const uint32_t qi = base + lane;
+        bool live = qi < total;
+        uint32_t id = 0;
+        PathState ps;
+        uint32_t slot;
+        if (FIRST) {
+            id = qi;
+            slot = live ? id / paths_per_sample : 0u;
+            const uint32_t local = id - slot * paths_per_sample;
+            const uint32_t tile = local >> 6;
+            const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
+            const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
+            live = live && (tx < fr.width) && (ty < fr.height);
+            ps.seed = pixel_seed(fr, tx, ty, samples[slot]);
+            const Ray cam = camera_ray(fr, tx, ty, ps.seed);
+            ps.o = cam.o; ps.d = cam.d;
+            ps.path = mk3(1.0f, 1.0f, 1.0f);
+            ps.energy = mk3(0.0f, 0.0f, 0.0f);
+            n_paths += live ? 1u : 0u;
+            if (!live && qi < total) store_path(b, id, ps);   // padding lanes: energy 0, never read back
+        } else {
+            id = live ? q[qi] : 0u;
+            load_path(b, id, ps);
+            ps.seed = b.s3[id].x;
+            slot = id / paths_per_sample;
+        }
+
+        Ray ray; ray.o = ps.o; ray.d = ps.d;
+        f4 isec;
+        const int hit = closest_hit_bf(sc, ray, isec);
+
+        bool to_shadow = false, to_glossy = false, to_next = false;
+        if (live) {
+            if (hit < 0) {
+                ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
+            } else {
+                const bool coin_diffuse = coins[slot * (uint32_t)max_depth + (uint32_t)depth] != 0u;
+                const float inv_det = 1.0f / isec.w;
+                Bounce bn;
+                shade_pre(sc, fr, ps, hit, isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, coin_diffuse, bn);
+                if (bn.kind == PROBE_NONE) {
+                    to_next = shade_post(sc, ps, hit, false, mk3(0.0f, 0.0f, 0.0f));
+                } else {
+                    b.p0[id] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
+                    b.p1[id] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
+                    to_shadow = bn.kind == PROBE_SHADOW;
+                    to_glossy = bn.kind == PROBE_GLOSSY;
+                }
+                b.s3[id] = make_uint2(ps.seed, (uint32_t)hit);
+            }
+            store_path(b, id, ps);
+        }
+        to_next = to_next && (depth + 1 < max_depth);
+        queue_push(b.q_shadow, cnt + 1, to_shadow, id);
+        queue_push(b.q_glossy, cnt + 2, to_glossy, id);
+        queue_push(q_next, cnt_next + 0, to_next, id);
+    }
+    if (FIRST) {
+        const unsigned long long p = wave_sum_u32(n_paths);
+        if (lane == 0 && p) { atomicAdd(&stats->pixel_samples, p); atomicAdd(&stats->rays, p); }
+    } else if (blockIdx.x == 0 && lane == 0) {
+        atomicAdd(&stats->rays, (unsigned long long)total);
+    }
+}
+
+// Shadow-probe stage: occlusion loop of sampleLight (raytracer.glsl:372-378), then :557-579.
+__global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, PipeBuffers b, int depth, int q_in, int max_depth,
+                                                     DStats *__restrict__ stats) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t *cnt = b.counters + 4 * depth;
+    uint32_t *cnt_next = b.counters + 4 * (depth + 1);
+    const uint32_t total = cnt[1];
+    uint32_t *q_next = b.q_ext[q_in ^ 1];
+    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+        const uint32_t qi = base + lane;
+        const bool live = qi < total;
+        const uint32_t id = live ? b.q_shadow[qi] : 0u;
+        const float4 a = b.s0[id], pr = b.p0[id];
+        const uint2 sc3 = b.s3[id];
+        Ray probe;
+        probe.o = mk3(a.x, a.y, a.z);
+        probe.d = mk3(pr.x, pr.y, pr.z);
+        const bool blocked = shadow_any_hit_bf(sc, probe, pr.w, (int)sc3.y, live);
+        bool to_next = false;
+        if (live) {
+            PathState ps;
+            load_path(b, id, ps);
+            ps.seed = sc3.x;
+            const float4 c = b.p1[id];
+            const bool has_light = !blocked;
+            const f3 gl = has_light ? mk3(c.x, c.y, c.z) : mk3(0.0f, 0.0f, 0.0f);
+            to_next = shade_post(sc, ps, (int)sc3.y, has_light, gl);
+            store_path(b, id, ps);
+            b.s3[id] = make_uint2(ps.seed, sc3.y);
+        }
+        to_next = to_next && (depth + 1 < max_depth);
+        queue_push(q_next, cnt_next + 0, to_next, id);
+    }
+    if (blockIdx.x == 0 && lane == 0) atomicAdd(&stats->shadow_probes, (unsigned long long)total);
+}
+
+// Glossy-probe stage: search loop of sampleLightGlossy (raytracer.glsl:403-437), then :557-579.
+__global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
+                                                     int max_depth, DStats *__restrict__ stats) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t *cnt = b.counters + 4 * depth;
+    uint32_t *cnt_next = b.counters + 4 * (depth + 1);
+    const uint32_t total = cnt[2];
+    uint32_t *q_next = b.q_ext[q_in ^ 1];
+    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+        const uint32_t qi = base + lane;
+        const bool live = qi < total;
+        const uint32_t id = live ? b.q_glossy[qi] : 0u;
+        const float4 a = b.s0[id], pr = b.p0[id];
+        const uint2 sc3 = b.s3[id];
+        Ray probe;
+        probe.o = mk3(a.x, a.y, a.z);
+        probe.d = mk3(pr.x, pr.y, pr.z);
+        int light_id;
+        f4 lsec;
+        const int outcome = glossy_search_bf(sc, probe, (int)sc3.y, live, light_id, lsec);
+        bool to_next = false;
+        if (live) {
+            PathState ps;
+            load_path(b, id, ps);
+            ps.seed = sc3.x;
+            const float4 c = b.p1[id];
+            Bounce bn;
+            bn.c = mk3(c.x, c.y, c.z);
+            bn.w = c.w;
+            const bool has_light = outcome != 0;
+            f3 gl = mk3(0.0f, 0.0f, 0.0f);
+            if (has_light) gl = glossy_global_light(bn, glossy_light(sc, fr, probe.d, outcome == 2 ? light_id : -1, lsec));
+            to_next = shade_post(sc, ps, (int)sc3.y, has_light, gl);
+            store_path(b, id, ps);
+            b.s3[id] = make_uint2(ps.seed, sc3.y);
+        }
+        to_next = to_next && (depth + 1 < max_depth);
+        queue_push(q_next, cnt_next + 0, to_next, id);
+    }
+    if (blockIdx.x == 0 && lane == 0) atomicAdd(&stats->glossy_probes, (unsigned long long)total);
+}
+
+// Resolve stage: sum[pixel] += energy of the batch's samples, ascending slot order.
+__global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restrict__ sum, uint32_t width,
+                                                 uint32_t height, uint32_t paths_per_sample, uint32_t n_slots) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= width * height) return;
+    const uint32_t tx = pix % width, ty = pix / width;
+    const uint32_t tiles_x = (width + 7u) >> 3;
+    const uint32_t local = ((ty >> 3) * tiles_x + (tx >> 3)) * 64u + (ty & 7u) * 8u + (tx & 7u);
+    float4 s = sum[pix];
+    for (uint32_t k = 0; k < n_slots; k++) {
+        const float4 e = b.s2[k * paths_per_sample + local];
+        s.x += e.y; s.y += e.z; s.z += e.w;
+    }
+    sum[pix] = s;
+}
+
+// Host side of the pipeline: buffers sized for one batch, and the launch sequence.
+struct Pipeline {
+    PipeBuffers buf = {};
+    size_t cap_paths = 0;
+    int cap_depth = 0;
+    uint32_t *d_coins = nullptr;
+    size_t cap_coins = 0;
+    uint32_t *h_count = nullptr;   // pinned, for the early-stop read-back
+    std::vector<hipEvent_t> events;
+
+    void release() {
+        (void)hipFree(buf.s0); (void)hipFree(buf.s1); (void)hipFree(buf.s2); (void)hipFree(buf.s3);
+        (void)hipFree(buf.p0); (void)hipFree(buf.p1);
+        (void)hipFree(buf.q_ext[0]); (void)hipFree(buf.q_ext[1]); (void)hipFree(buf.q_shadow); (void)hipFree(buf.q_glossy);
+        (void)hipFree(buf.counters);
+        (void)hipFree(d_coins);
+        if (h_count) (void)hipHostFree(h_count);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        events.clear();
+        buf = PipeBuffers{};
+        d_coins = nullptr;
+        h_count = nullptr;
+        cap_paths = 0; cap_depth = 0; cap_coins = 0;
+    }
+
+    hipError_t ensure(size_t paths, int depth, size_t coins, const char **what) {
+        hipError_t e = hipSuccess;
+#define PIPE_ALLOC(ptr, bytes) do { *what = #ptr; e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
+        if (paths > cap_paths) {
+            (void)hipFree(buf.s0); (void)hipFree(buf.s1); (void)hipFree(buf.s2); (void)hipFree(buf.s3);
+            (void)hipFree(buf.p0); (void)hipFree(buf.p1);
+            (void)hipFree(buf.q_ext[0]); (void)hipFree(buf.q_ext[1]); (void)hipFree(buf.q_shadow); (void)hipFree(buf.q_glossy);
+            buf.s0 = buf.s1 = buf.s2 = buf.p0 = buf.p1 = nullptr; buf.s3 = nullptr;
+            buf.q_ext[0] = buf.q_ext[1] = buf.q_shadow = buf.q_glossy = nullptr;
+            cap_paths = 0;
+            PIPE_ALLOC(buf.s0, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.s1, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.s2, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.s3, sizeof(uint2) * paths);
+            PIPE_ALLOC(buf.p0, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.p1, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.q_ext[0], sizeof(uint32_t) * paths);
+            PIPE_ALLOC(buf.q_ext[1], sizeof(uint32_t) * paths);
+            PIPE_ALLOC(buf.q_shadow, sizeof(uint32_t) * paths);
+            PIPE_ALLOC(buf.q_glossy, sizeof(uint32_t) * paths);
+            cap_paths = paths;
+        }
+        if (depth > cap_depth) {
+            (void)hipFree(buf.counters);
+            buf.counters = nullptr;
+            cap_depth = 0;
+            PIPE_ALLOC(buf.counters, sizeof(uint32_t) * 4 * (size_t)(depth + 2));
+            cap_depth = depth;
+        }
+        if (coins > cap_coins) {
+            (void)hipFree(d_coins);
+            d_coins = nullptr;
+            cap_coins = 0;
+            PIPE_ALLOC(d_coins, sizeof(uint32_t) * coins);
+            cap_coins = coins;
+        }
+        if (!h_count) {
+            *what = "h_count";
+            e = hipHostMalloc((void **)&h_count, sizeof(uint32_t) * 4);
+            if (e != hipSuccess) return e;
+        }
+#undef PIPE_ALLOC
+        return hipSuccess;
+    }
+
+    // Renders the `n` samples listed in d_samples (light seeds in h_light_seeds order) and adds them to `sum`.
+    hipError_t run(const DScene &sc, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
+                   const uint32_t *d_light_seeds, int n, DStats *d_stats, hipStream_t stream, bool profiling,
+                   rt_stats *host_stats, const char **what);
+
+    // light seeds are also needed on the host to tabulate the per-depth coin; set before run()
+    std::vector<uint32_t> h_light_seeds;
+};
+
+inline hipError_t Pipeline::run(const DScene &sc, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
+                                const uint32_t *d_light_seeds, int n, DStats *d_stats, hipStream_t stream,
+                                bool profiling, rt_stats *host_stats, const char **what) {
+    (void)d_light_seeds;
+    const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
+    const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
+    const uint32_t pps = tiles * 64u;
+    const size_t paths = (size_t)pps * (size_t)n;
+    if (paths > 0xFFFFFFF0ull) { *what = "batch has more than 2^32 paths"; return hipErrorInvalidValue; }
+    hipError_t e = ensure(paths, max_depth, (size_t)n * max_depth, what);
+    if (e != hipSuccess) return e;
+
+    // coin[slot][depth] = unitFloat(light_seed) < 0.5 after `depth` earlier draws (raytracer.glsl:553)
+    std::vector<uint32_t> coins((size_t)n * max_depth);
+    for (int k = 0; k < n; k++) {
+        uint32_t ls = h_light_seeds[k];
+        for (int d = 0; d < max_depth; d++) {
+            const uint32_t state = ls * 747796405u + 2891336453u;
+            const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+            ls = (word >> 22u) ^ word;
+            coins[(size_t)k * max_depth + d] = ((float)ls * (1.0f / 4294967296.0f) < 0.5f) ? 1u : 0u;
+        }
+    }
+#define PIPE_TRY(expr) do { *what = #expr; e = (expr); if (e != hipSuccess) return e; } while (0)
+    PIPE_TRY(hipMemcpyAsync(d_coins, coins.data(), sizeof(uint32_t) * coins.size(), hipMemcpyHostToDevice, stream));
+    PIPE_TRY(hipStreamSynchronize(stream));   // `coins` is a local
+    PIPE_TRY(hipMemsetAsync(buf.counters, 0, sizeof(uint32_t) * 4 * (size_t)(max_depth + 2), stream));
+
+    size_t ev_used = 0;
+    auto stamp = [&]() -> hipError_t {
+        if (!profiling) return hipSuccess;
+        if (ev_used == events.size()) {
+            hipEvent_t ev;
+            hipError_t ee = hipEventCreate(&ev);
+            if (ee != hipSuccess) return ee;
+            events.push_back(ev);
+        }
+        return hipEventRecord(events[ev_used++], stream);
+    };
+    std::vector<int> kinds;   // per event interval: 0 extend, 1 probe
+
+    const uint32_t chunks0 = (uint32_t)((paths + 63) / 64);
+    const dim3 grid0(chunks0 < (uint32_t)PIPE_WAVES ? chunks0 : (uint32_t)PIPE_WAVES), grid(PIPE_WAVES), block(64);
+    int q_in = 0;
+    for (int depth = 0; depth < max_depth; depth++) {
+        PIPE_TRY(stamp());
+        if (depth == 0)
+            hipLaunchKernelGGL(k_extend<true>, grid0, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins, pps,
+                               (uint32_t)n, max_depth, d_stats);
+        else
+            hipLaunchKernelGGL(k_extend<false>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins, pps,
+                               (uint32_t)n, max_depth, d_stats);
+        PIPE_TRY(hipGetLastError());
+        PIPE_TRY(stamp());
+        hipLaunchKernelGGL(k_probe_shadow, grid, block, 0, stream, sc, buf, depth, q_in, max_depth, d_stats);
+        PIPE_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_probe_glossy, grid, block, 0, stream, sc, fr, buf, depth, q_in, max_depth, d_stats);
+        PIPE_TRY(hipGetLastError());
+        PIPE_TRY(stamp());
+        if (profiling) { kinds.push_back(0); kinds.push_back(1); kinds.push_back(-1); }
+        q_in ^= 1;
+        // deep paths are rare: from depth 4 on, stop as soon as the next extend queue is empty
+        if (depth >= 3 && depth + 1 < max_depth) {
+            PIPE_TRY(hipMemcpyAsync(h_count, buf.counters + 4 * (depth + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            PIPE_TRY(hipStreamSynchronize(stream));
+            if (h_count[0] == 0) break;
+        }
+    }
+    hipLaunchKernelGGL(k_resolve, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
+                       fr.height, pps, (uint32_t)n);
+    PIPE_TRY(hipGetLastError());
+
+    if (profiling && ev_used >= 2) {
+        PIPE_TRY(hipEventSynchronize(events[ev_used - 1]));
+        for (size_t i = 0; i + 1 < ev_used; i++) {
+            if (kinds[i] < 0) continue;
+            float ms = 0.0f;
+            PIPE_TRY(hipEventElapsedTime(&ms, events[i], events[i + 1]));
+            if (kinds[i] == 0) { host_stats->extend_ms += ms; host_stats->extend_launches++; }
+            else { host_stats->probe_ms += ms; host_stats->probe_launches += 2; }
+        }
+    }
+#undef PIPE_TRY
+    return hipSuccess;
+}
+
+}  // namespace rt

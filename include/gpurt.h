@@ -1,0 +1,169 @@
+/*
+ * gpurt.h - C ABI of the MI355X path-tracing core (libgpurt.so).
+ *
+ * The reference renderer has no plugin or FFI layer: its compute path tracer
+ * (res/shader/raytracer.glsl) sits behind six methods of class Scene that talk
+ * straight to OpenGL.  Each entry point below replaces the OpenGL traffic of one of
+ * those methods; the comment on each names the reference interface it stands for.
+ *
+ * Conventions
+ *   - Every function returns RT_OK (0) or a negative rt_status; rt_last_error()
+ *     gives the text of the last failure on that context.
+ *   - A context is bound to one GPU and may be used from one host thread at a time.
+ *   - Host pointers passed in are copied before the call returns; the caller keeps
+ *     ownership.  rt_trace() is asynchronous on the context's stream;
+ *     rt_read_sum(), rt_synchronize() and rt_get_stats() wait for it.
+ *   - The three record types are byte-identical to the reference's SSBO layouts.
+ */
+#ifndef GPURT_H
+#define GPURT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument */
+    RT_ERR_STATE = -2,     /* call order: no scene, no frame, no target ... */
+    RT_ERR_DEVICE = -3,    /* a HIP call failed */
+    RT_ERR_NOMEM = -4,
+    RT_ERR_LIMIT = -5      /* size beyond a documented maximum */
+} rt_status;
+
+/* TriangleModel: 3Dobjects.hpp:102-113, raytracer.glsl:13-18.  48 bytes. */
+typedef struct rt_triangle_model {
+    float true_normal[3];  /* cross(u, v), not normalised */
+    float position[3];
+    float u[3];
+    float v[3];
+} rt_triangle_model;
+
+/* TriangleShading: 3Dobjects.hpp:115-135, raytracer.glsl:20-29.  100 bytes. */
+typedef struct rt_triangle_shading {
+    uint32_t material_id;
+    float normals[3][3];
+    float tangents[3][3];
+    float tex_p[2];
+    float tex_u[2];
+    float tex_v[2];
+} rt_triangle_shading;
+
+/* Material: Material.hpp:9-15, raytracer.glsl:36-40.  48 bytes. */
+typedef struct rt_material {
+    float albedo[4];              /* rgb, a unused */
+    float specular_roughness[4];  /* rgb = Ks, a = Ns / 1000 */
+    float emission_ior[4];        /* rgb = Ke, a = Ni */
+} rt_material;
+
+/* Work counters of the launches since the last rt_resize()/rt_reset_stats(). */
+typedef struct rt_stats {
+    uint64_t pixel_samples;     /* camera paths started */
+    uint64_t rays;              /* findIntersection executions (paths x bounces) */
+    uint64_t shadow_probes;     /* sampleLight calls that reached the occlusion loop */
+    uint64_t glossy_probes;     /* sampleLightGlossy calls */
+    uint64_t closest_tests;     /* ray-triangle closest-hit tests charged (brute force: rays * COUNT) */
+    uint64_t probe_tests;       /* ray-triangle probe tests charged */
+    double   trace_ms;          /* device time of all rt_trace kernels (HIP events on the context stream) */
+    double   extend_ms;         /* part of trace_ms spent in closest-hit kernels */
+    double   probe_ms;          /* part of trace_ms spent in light-probe kernels */
+    uint64_t extend_launches;
+    uint64_t probe_launches;
+} rt_stats;
+
+typedef struct rt_context rt_context;
+
+/* Lifetime.  `device` is the HIP device ordinal.  Scene::Scene / Scene::~Scene
+ * (Scene.cpp:231-280) own every GL object in the reference; the context owns every
+ * device allocation here. */
+int rt_create(int device, rt_context **out);
+int rt_destroy(rt_context *ctx);
+const char *rt_last_error(const rt_context *ctx);
+
+/* Launch subsequent work on `hip_stream` (a hipStream_t, or NULL for the context's own). */
+int rt_set_stream(rt_context *ctx, void *hip_stream);
+int rt_synchronize(rt_context *ctx);
+
+/* Scene::finalizeObjects -> createTrianglesBuffers (Scene.cpp:382-395, :343-346):
+ * the three immutable SSBOs plus the COUNT (:362) and LIGHTS (:293) uniforms.
+ * Triangles [0, lights) are the emissive ones.  Records are re-laid-out to SoA on
+ * the device. */
+int rt_upload_scene(rt_context *ctx,
+                    const rt_triangle_model *models, const rt_triangle_shading *shadings,
+                    uint32_t count, uint32_t lights,
+                    const rt_material *materials, uint32_t n_materials);
+
+/* Scene::createRTCSData atlas allocation (Scene.cpp:364-370).  The reference atlas is
+ * 4096 x 4096 x (3 * materials) texels of R11F_G11F_B10F; `size` selects the edge
+ * length (4096 by default).  Layers are allocated when first uploaded. */
+int rt_set_atlas_size(rt_context *ctx, uint32_t size);
+
+/* Scene::loadTexture (Scene.cpp:75-102): RGBA32F host pixels -> texels [0,w) x [0,h)
+ * of layer material*3 + slot (slot 0 albedo, 1 normal, 2 occlusion/roughness/metallic),
+ * converted to packed 11/11/10-bit unsigned floats. */
+int rt_upload_atlas_layer(rt_context *ctx, uint32_t material, uint32_t slot,
+                          uint32_t w, uint32_t h, const float *rgba);
+
+/* Scene::loadMaterial's glNamedBufferSubData(hasTextureBuffer, ...) (Scene.cpp:227). */
+int rt_set_has_texture(rt_context *ctx, const int32_t *flags, uint32_t n);
+
+/* Scene::loadEnvironmentTexture (Scene.cpp:104-160): RGBA32F, bilinear, repeat. */
+int rt_upload_env(rt_context *ctx, uint32_t w, uint32_t h, const float *rgba);
+
+/* Scene::adaptResolution (Scene.cpp:397-421): (re)allocate the accumulation target
+ * and clear it.  The target holds per-pixel SUMS of sample radiance, not the
+ * reference's running mean, so that partial results from several launches or
+ * several GPUs add. */
+int rt_resize(rt_context *ctx, uint32_t width, uint32_t height);
+
+/* Accumulate into caller-owned device memory (width*height float4, rgb = sums)
+ * instead of the context's own buffer; NULL restores the internal one.  Lets a
+ * host keep the buffer in a tensor it can hand to a collective. */
+int rt_set_sum_buffer(rt_context *ctx, float *device_rgba);
+
+/* Scene::prepare (Scene.cpp:435-464): CAMERA (16 floats, column-major),
+ * CLOCK, RECURSION, and the EXPOSURE uniform set at Scene.cpp:331. */
+int rt_set_frame(rt_context *ctx, const float camera[16], uint32_t clock,
+                 int32_t recursion, float exposure);
+
+/* Scene::traceScene (Scene.cpp:423-433), one reference dispatch per sample index:
+ * renders SAMPLE = sample_begin + k * sample_stride for k in [0, sample_count)
+ * and adds each sample's radiance to the sum buffer. */
+int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count,
+             uint32_t sample_stride);
+
+/* Scene::exportEXR's glGetTextureImage(GL_RGB, GL_FLOAT) (Scene.cpp:496-509):
+ * copies width*height*3 floats (row 0 = TEXEL.y 0, as the reference writes them)
+ * and the number of samples summed per pixel. */
+int rt_read_sum(rt_context *ctx, float *rgb, uint64_t *n_samples);
+
+/* No counterpart in the reference (findIntersection, raytracer.glsl:217-235, cannot be
+ * called on its own there): closest hit for a batch of rays.  o_xyz/d_xyz are n*3
+ * floats, id gets the triangle index (-1 = miss), uvt gets n*3 floats (u, v, t). */
+int rt_closest_hit_batch(rt_context *ctx, const float *o_xyz, const float *d_xyz,
+                         uint64_t n, int32_t *id, float *uvt);
+
+/* Same with all four arrays already in device memory (asynchronous). */
+int rt_closest_hit_batch_device(rt_context *ctx, const float *o_xyz, const float *d_xyz,
+                                uint64_t n, int32_t *id, float *uvt);
+
+/* displayQuad.fs:19-34: sRGB transfer of sum / n_samples to 8-bit RGB (row order as rt_read_sum). */
+int rt_read_srgb8(rt_context *ctx, uint8_t *rgb);
+
+int rt_get_stats(rt_context *ctx, rt_stats *out);
+int rt_reset_stats(rt_context *ctx);
+
+/* Tuning knobs; unknown names return RT_ERR_INVALID.
+ *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
+ *                   1 = staged kernels over compacted ray queues (default)
+ *   "batch_samples" samples rendered per pass of the staged pipeline (default 4)
+ *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
+int rt_set_option(rt_context *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPURT_H */

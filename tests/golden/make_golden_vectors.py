@@ -1,0 +1,82 @@
+"""Writes the golden vectors under tests/golden/ with the CPU checker (oracle/, deterministic math
+back end):
+  rays_<scene>.npz   4096 rays (origins, directions) with closest-hit ids and (u, v, t)
+  image_cubes_<spp>spp.npz  64x64 per-pixel radiance SUMS of SAMPLE 0..spp-1, constant environment,
+                     CLOCK 95834783, RECURSION 6, plus the ray/probe counters of that render
+Run in the build container:  python tests/golden/make_golden_vectors.py
+These pin this repository's own restatement (the reference has no fixtures for this path); a
+change of a vector means the arithmetic contract changed and has to be deliberate.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(HERE, ".."))
+from conftest import constant_env, load_scene  # noqa: E402
+from gpuraytracer_amd.camera import camera_matrix, DEFAULT_CLOCK  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def ray_batch(models, n=4096, seed=7):
+    """Fixed batch: camera-like rays, random interior rays, and rays aimed exactly at vertices,
+    edge midpoints and coincident copies (the tie cases of the closest-hit fold)."""
+    rng = np.random.default_rng(seed)
+    p0 = models["position"]
+    p1 = p0 + models["u"]
+    p2 = p0 + models["v"]
+    pts = np.concatenate([p0, p1, p2])
+    lo, hi = pts.min(0), pts.max(0)
+    cam = camera_matrix().reshape(4, 4).T.astype(np.float64)
+    o, d = [], []
+    q = n // 4
+    # camera rays (two quarters)
+    for _ in range(2 * q):
+        x, y = rng.uniform(-1.2, 1.2), rng.uniform(-0.5, 0.5)
+        v = np.array([x, y, 0.5])
+        v /= np.linalg.norm(v)
+        o.append(cam[:3, 3])
+        d.append(cam[:3, :3] @ v)
+    # random rays inside the bounding box
+    for _ in range(q):
+        o.append(rng.uniform(lo, hi))
+        v = rng.normal(size=3)
+        d.append(v / np.linalg.norm(v))
+    # aimed rays: vertices, edge midpoints, centroids
+    tri = rng.integers(0, len(models), size=n - 3 * q)
+    for k, t in enumerate(tri):
+        org = rng.uniform(lo, hi)
+        a, b, c = p0[t].astype(np.float64), p1[t].astype(np.float64), p2[t].astype(np.float64)
+        target = [a, b, c, 0.5 * (a + b), 0.5 * (b + c), 0.5 * (a + c), (a + b + c) / 3.0][k % 7]
+        v = target - org
+        nv = np.linalg.norm(v)
+        d.append(v / nv if nv > 0 else np.array([0.0, 0.0, 1.0]))
+        o.append(org)
+    return np.array(o, dtype=np.float32), np.array(d, dtype=np.float32)
+
+
+def main():
+    oracle.build()
+    for name in ("cubes", "_ObiWan"):
+        models, shadings, lights, materials = load_scene(name)
+        sc = oracle.OracleScene(models, shadings, lights, materials)
+        o, d = ray_batch(models)
+        ids, uvt = sc.closest_hit_batch(o, d)
+        np.savez_compressed(os.path.join(HERE, "rays_%s.npz" % name), o=o, d=d, ids=ids, uvt=uvt)
+        print(name, "hits", int((ids >= 0).sum()), "of", len(ids))
+    models, shadings, lights, materials = load_scene("cubes")
+    sc = oracle.OracleScene(models, shadings, lights, materials)
+    sc.upload_env(constant_env())
+    cam = camera_matrix()
+    for spp in (1, 4, 16):
+        img, st = sc.render(cam, DEFAULT_CLOCK, 6, 1.0, 64, 64, 0, spp)
+        np.savez_compressed(os.path.join(HERE, "image_cubes_%dspp.npz" % spp), rgb_sum=img,
+                            stats=np.array([st["pixel_samples"], st["rays"], st["shadow_probes"],
+                                            st["glossy_probes"]], dtype=np.uint64))
+        print("cubes", spp, "spp", st, float(img.mean()))
+
+
+if __name__ == "__main__":
+    main()

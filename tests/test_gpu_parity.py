@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU checker and the
+committed golden vectors.  Bit-exact for hit ids, (u, v, t), ray counters and radiance sums (the
+device and the checker's deterministic back end evaluate the same IEEE operation sequence); a
+relative-RMSE bound against the checker's C-library back end."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, constant_env, gradient_env, load_scene
+from gpuraytracer_amd.camera import camera_matrix, DEFAULT_CLOCK
+
+pytestmark = pytest.mark.gpu
+
+CAM = camera_matrix()
+
+
+def _upload(ctx, scene, env):
+    models, shadings, lights, materials = scene
+    ctx.upload_scene(models, shadings, lights, materials)
+    ctx.upload_env(env)
+
+
+def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM):
+    ctx.set_option("pipeline", pipeline)
+    ctx.set_option("batch_samples", batch)
+    ctx.resize(w, h)
+    ctx.set_frame(cam, clock, recursion, 1.0)
+    ctx.trace(begin, count, stride)
+    img, n = ctx.read_sum()
+    assert n == count
+    return img, ctx.stats()
+
+
+@pytest.mark.parametrize("name", ["cubes", "_ObiWan"])
+def test_closest_hit_ids_bit_exact(gpu_ctx, oracle_mod, name):
+    g = np.load(os.path.join(GOLDEN, "rays_%s.npz" % name))
+    scene = load_scene(name)
+    _upload(gpu_ctx, scene, constant_env())
+    ids, uvt = gpu_ctx.closest_hit_batch(g["o"], g["d"])
+    assert np.array_equal(ids, g["ids"])
+    assert np.array_equal(uvt.view(np.uint32), g["uvt"].view(np.uint32))
+    # and against the checker run now, on a second seeded batch
+    rng = np.random.default_rng(11)
+    o = rng.uniform(-4, 4, size=(3000, 3)).astype(np.float32)
+    d = rng.normal(size=(3000, 3)).astype(np.float32)
+    sc = oracle_mod.OracleScene(*scene)
+    want_ids, want_uvt = sc.closest_hit_batch(o, d)
+    ids, uvt = gpu_ctx.closest_hit_batch(o, d)
+    assert np.array_equal(ids, want_ids) and np.array_equal(uvt.view(np.uint32), want_uvt.view(np.uint32))
+
+
+def test_closest_hit_edge_cases(gpu_ctx, oracle_mod, cubes):
+    _upload(gpu_ctx, cubes, constant_env())
+    sc = oracle_mod.OracleScene(*cubes)
+    # empty batch, one ray, a batch that is not a multiple of the block size, NaN / zero directions
+    ids, uvt = gpu_ctx.closest_hit_batch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert len(ids) == 0
+    o = np.array([[0, 1.5, -3], [np.nan, 0, 0], [0, 0, 0], [0, 1.5, -3]], np.float32)
+    d = np.array([[0, -0.7, 0.7], [0, 0, 1], [0, 0, 0], [np.inf, 0, 0]], np.float32)
+    ids, uvt = gpu_ctx.closest_hit_batch(o, d)
+    want_ids, want_uvt = sc.closest_hit_batch(o, d)
+    assert np.array_equal(ids, want_ids)
+    assert np.array_equal(uvt, want_uvt, equal_nan=True)
+    assert ids[1] == len(cubes[0]) - 1          # a NaN ray passes every rejection: last triangle wins
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
+    _upload(gpu_ctx, cubes, constant_env())
+    for spp in (1, 4, 16):
+        g = np.load(os.path.join(GOLDEN, "image_cubes_%dspp.npz" % spp))
+        img, st = _render(gpu_ctx, 64, 64, 0, spp, pipeline=pipeline)
+        assert np.array_equal(img, g["rgb_sum"]), (pipeline, spp, float(np.abs(img - g["rgb_sum"]).max()))
+        assert [st["pixel_samples"], st["rays"], st["shadow_probes"], st["glossy_probes"]] == g["stats"].tolist()
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_image_vs_checker_gradient_env_ragged(gpu_ctx, oracle_mod, cubes, pipeline):
+    # 52 x 37 is not a multiple of the 8 x 8 tile; the gradient environment exercises the bilinear lookup
+    _upload(gpu_ctx, cubes, gradient_env())
+    sc = oracle_mod.OracleScene(*cubes)
+    sc.upload_env(gradient_env())
+    cam = camera_matrix((0.3, 1.2, -2.5), (-0.5, 0.4))
+    want, wst = sc.render(cam, 12345, 6, 1.0, 52, 37, 0, 6)
+    img, st = _render(gpu_ctx, 52, 37, 0, 6, clock=12345, pipeline=pipeline, batch=4, cam=cam)
+    assert np.array_equal(img, want), float(np.abs(img - want).max())
+    for k in ("pixel_samples", "rays", "shadow_probes", "glossy_probes"):
+        assert st[k] == wst[k], k
+    # tolerance against the independent C-library back end: relative RMSE of the 6-spp image
+    sl = oracle_mod.OracleScene(*cubes, libm=True)
+    sl.upload_env(gradient_env())
+    ref, _ = sl.render(cam, 12345, 6, 1.0, 52, 37, 0, 6)
+    assert np.sqrt(np.mean((img - ref) ** 2)) / np.mean(ref) < 0.02
+
+
+def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
+    # glass (Ni 1.474) and rough metals, RECURSION 16: Fresnel, metallic and roulette branches
+    _upload(gpu_ctx, obiwan, gradient_env())
+    sc = oracle_mod.OracleScene(*obiwan)
+    sc.upload_env(gradient_env())
+    cam = camera_matrix((0.0, 1.0, -2.0), (-0.3, 0.0))
+    want, wst = sc.render(cam, DEFAULT_CLOCK, 16, 1.0, 32, 24, 0, 3)
+    for pipeline in (0, 1):
+        img, st = _render(gpu_ctx, 32, 24, 0, 3, recursion=16, pipeline=pipeline, batch=2, cam=cam)
+        assert np.array_equal(img, want, equal_nan=True), pipeline
+        assert st["rays"] == wst["rays"] and st["glossy_probes"] == wst["glossy_probes"]
+
+
+def test_box_scene_without_lights(gpu_ctx, oracle_mod):
+    scene = load_scene("box")
+    _upload(gpu_ctx, scene, constant_env())
+    sc = oracle_mod.OracleScene(*scene)
+    sc.upload_env(constant_env())
+    want, wst = sc.render(CAM, 777, 6, 1.0, 48, 48, 0, 4)
+    img, st = _render(gpu_ctx, 48, 48, 0, 4, clock=777)
+    assert np.array_equal(img, want)
+    assert st["shadow_probes"] == 0 and st["rays"] == wst["rays"]
+
+
+def test_launch_chaining_and_sample_split(gpu_ctx, cubes):
+    _upload(gpu_ctx, cubes, constant_env())
+    full, _ = _render(gpu_ctx, 64, 40, 0, 12, batch=5)
+    # the same 12 samples in three launches and another batch size: same bits
+    gpu_ctx.resize(64, 40)
+    gpu_ctx.set_option("batch_samples", 3)
+    gpu_ctx.set_frame(CAM, DEFAULT_CLOCK, 6, 1.0)
+    gpu_ctx.trace(0, 5, 1)
+    gpu_ctx.trace(5, 4, 1)
+    gpu_ctx.trace(9, 3, 1)
+    part, n = gpu_ctx.read_sum()
+    assert n == 12 and np.array_equal(part, full)
+    # the multi-GPU split (SAMPLE = rank mod N) emulated on one device: per-rank sums add up to the full image
+    acc = np.zeros_like(full, dtype=np.float64)
+    for rank in range(3):
+        part, _ = _render(gpu_ctx, 64, 40, rank, 4, stride=3)
+        acc += part
+    assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
+
+
+def test_textured_materials_bit_exact(gpu_ctx, oracle_mod, cubes):
+    # synthetic albedo / normal / ARM layers on the Wall material, small atlas
+    models, shadings, lights, materials = cubes
+    rng = np.random.default_rng(5)
+    S = 32
+    # give the triangles texture coordinates that span the layer
+    shadings = shadings.copy()
+    shadings["tex_p"] = rng.uniform(0, 1, size=(len(shadings), 2)).astype(np.float32)
+    shadings["tex_u"] = rng.uniform(-2, 2, size=(len(shadings), 2)).astype(np.float32)
+    shadings["tex_v"] = rng.uniform(-2, 2, size=(len(shadings), 2)).astype(np.float32)
+    t = rng.normal(size=(len(shadings), 3, 3)).astype(np.float32)
+    shadings["tangents"] = t / np.linalg.norm(t, axis=2, keepdims=True)
+    albedo = rng.uniform(0.1, 0.9, size=(S, S, 4)).astype(np.float32)
+    nrm = rng.uniform(0.3, 0.7, size=(S, S, 4)).astype(np.float32)
+    nrm[..., 2] = rng.uniform(0.8, 1.0, size=(S, S))
+    arm = rng.uniform(0.05, 1.0, size=(24, 20, 4)).astype(np.float32)     # smaller than the layer: corner only
+    gpu_ctx.upload_scene(models, shadings, lights, materials)
+    gpu_ctx.upload_env(gradient_env())
+    gpu_ctx.set_atlas_size(S)
+    sc = oracle_mod.OracleScene(models, shadings, lights, materials)
+    sc.upload_env(gradient_env())
+    sc.set_atlas_size(S)
+    for target in (gpu_ctx, sc):
+        target.upload_atlas_layer(2, 0, albedo)
+        target.upload_atlas_layer(2, 1, nrm)
+        target.upload_atlas_layer(2, 2, arm)
+        target.set_has_texture(np.array([0, 0, 1, 0], np.int32))
+    want, wst = sc.render(CAM, 4242, 6, 1.0, 48, 32, 0, 4)
+    for pipeline in (0, 1):
+        img, st = _render(gpu_ctx, 48, 32, 0, 4, clock=4242, pipeline=pipeline)
+        assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
+        assert st["rays"] == wst["rays"]
+    gpu_ctx.set_atlas_size(4096)
+
+
+def test_srgb8_readback(gpu_ctx, oracle_mod, cubes):
+    _upload(gpu_ctx, cubes, constant_env())
+    img, _ = _render(gpu_ctx, 32, 32, 0, 4)
+    rgb8 = gpu_ctx.read_srgb8()
+    mean = img / 4.0
+    want = np.vectorize(oracle_mod.linear_to_srgb)(mean.astype(np.float64)).astype(np.float64)
+    want8 = np.clip(np.floor(want * 255.0 + 0.5), 0, 255)
+    assert np.abs(rgb8.astype(np.int32) - want8.astype(np.int32)).max() <= 1     # displayQuad.fs:19-25, +-1 code
+
+
+def test_error_behaviour(oracle_mod, cubes):
+    import gpuraytracer_amd as g
+    ctx = g.Context(0)
+    try:
+        with pytest.raises(g.GpuRtError):       # no scene yet
+            ctx.trace(0, 1, 1)
+        models, shadings, lights, materials = cubes
+        with pytest.raises(g.GpuRtError):       # lights > count
+            ctx.upload_scene(models[:4], shadings[:4], 5, materials)
+        bad = shadings[:4].copy()
+        bad["material_id"] = 9
+        with pytest.raises(g.GpuRtError):       # material id out of range
+            ctx.upload_scene(models[:4], bad, 0, materials)
+        ctx.upload_scene(models, shadings, lights, materials)
+        with pytest.raises(g.GpuRtError):       # no frame / no target
+            ctx.trace(0, 1, 1)
+        ctx.resize(8, 8)
+        ctx.set_frame(CAM, 1, 6, 1.0)
+        with pytest.raises(g.GpuRtError):
+            ctx.trace(0, 1, 0)                  # stride 0
+        with pytest.raises(g.GpuRtError):
+            ctx.set_option("no_such_option", 1)
+        ctx.trace(0, 0, 1)                      # zero samples is a no-op
+        ctx.upload_env(constant_env())
+        ctx.trace(0, 1, 1)
+        img, n = ctx.read_sum()
+        assert n == 1 and np.isfinite(img).all()
+    finally:
+        ctx.close()
