@@ -56,13 +56,13 @@ def test_closest_hit_edge_cases(gpu_ctx, oracle_mod, cubes):
     # empty batch, one ray, a batch that is not a multiple of the block size, NaN / zero directions
     ids, uvt = gpu_ctx.closest_hit_batch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
     assert len(ids) == 0
-    o = np.array([[0, 1.5, -3], [np.nan, 0, 0], [0, 0, 0], [0, 1.5, -3]], np.float32)
-    d = np.array([[0, -0.7, 0.7], [0, 0, 1], [0, 0, 0], [np.inf, 0, 0]], np.float32)
+    o = np.array([[0, 1.5, -3], [np.nan] * 3, [0, 0, 0], [0, 1.5, -3], [np.nan, 0, 0]], np.float32)
+    d = np.array([[0, -0.7, 0.7], [np.nan] * 3, [0, 0, 0], [np.inf, 0, 0], [0, 0, 1]], np.float32)
     ids, uvt = gpu_ctx.closest_hit_batch(o, d)
     want_ids, want_uvt = sc.closest_hit_batch(o, d)
     assert np.array_equal(ids, want_ids)
     assert np.array_equal(uvt, want_uvt, equal_nan=True)
-    assert ids[1] == len(cubes[0]) - 1          # a NaN ray passes every rejection: last triangle wins
+    assert ids[1] == len(cubes[0]) - 1          # an all-NaN ray passes every rejection: last triangle wins
 
 
 @pytest.mark.parametrize("pipeline", [0, 1])

@@ -83,7 +83,7 @@ def test_nan_ray_hits_last_triangle(oracle_mod):
     # every rejection is written as a comparison that is false for NaN, so a NaN ray "hits" everything
     m1, s1, mat = _single_triangle()
     sc = oracle_mod.OracleScene(np.concatenate([m1, m1]), np.concatenate([s1, s1]), 0, mat)
-    ids, uvt = sc.closest_hit_batch(np.array([[np.nan, 0, 1]], np.float32), np.array([[0, 0, -1]], np.float32))
+    ids, uvt = sc.closest_hit_batch(np.array([[np.nan] * 3], np.float32), np.array([[np.nan] * 3], np.float32))
     assert ids[0] == 1 and np.isnan(uvt[0]).any()
 
 
