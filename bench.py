@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (paths x bounces) of the path tracer at 1080p.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the reference's bundled `cubes` scene (424 triangles, 24 of
+them emissive), 1920x1080, RECURSION 6, CLOCK 95834783, default camera, constant environment
+(the reference's .exr environment is not in its repository; data is synthetic in that sense).
+One step renders `--spp-per-step` samples per pixel (64 by default); the default 16 steps are the
+1024 spp of the metric, so `seconds_to_1024spp` is the timed region itself.  Rays = findIntersection
+executions (one per bounce entered); light probes are counted separately.
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders the same number
+of samples per pixel with SAMPLE = rank + N*k (weak scaling), the scene is replicated, and the
+per-GPU radiance sums are added onto rank 0 by one RCCL reduce inside the timed region.
+
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+RECURSION = 6
+# FP32 vector rate without fused multiply-add: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (one flop per lane
+# and issue slot); half of the 157.3 TFLOP/s FMA figure.  The intersection arithmetic may not contract.
+PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+FLOPS_PER_CLOSEST_TEST = 35     # raytracer.glsl:135-158, full pass
+FLOPS_PER_PROBE_TEST = 34       # raytracer.glsl:171-195
+
+
+def constant_env():
+    env = np.zeros((4, 8, 4), dtype=np.float32)
+    env[..., 0], env[..., 1], env[..., 2], env[..., 3] = 0.5, 0.7, 1.0, 1.0
+    return env
+
+
+def cpu_baseline(scene, cam, clock, budget_s=12.0):
+    """The CPU restatement (oracle/, C-library math, OpenMP) on a bounded sample of the same workload:
+    whole 1080p frames of consecutive SAMPLE indices, as many as fit the time budget."""
+    from oracle import oracle
+    sc = oracle.OracleScene(*scene, libm=True)
+    sc.upload_env(constant_env())
+    t0 = time.perf_counter()
+    _, st = sc.render(cam, clock, RECURSION, 1.0, W, H, 0, 1)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(32, budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    _, st = sc.render(cam, clock, RECURSION, 1.0, W, H, 0, spp)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d, SAMPLE 0..%d (%d rays) in %.2f s, OpenMP over pixels" % (W, H, spp - 1, st["rays"], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--batch-samples", type=int, default=4)
+    ap.add_argument("--pipeline", type=int, default=1)
+    ap.add_argument("--fuse-shade", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gpuraytracer_amd as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    scene = g.read_rtscene(os.path.join(ROOT, "tests", "golden", "scenes", "cubes.rtscene"))
+    cam = g.camera_matrix()
+    clock = g.DEFAULT_CLOCK
+
+    ctx = g.Context(local_rank)
+    ctx.set_option("pipeline", args.pipeline)
+    ctx.set_option("batch_samples", args.batch_samples)
+    ctx.set_option("fuse_shade", args.fuse_shade)
+    ctx.set_option("profiling", 1)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.upload_scene(*scene)
+    ctx.upload_env(constant_env())
+    ctx.resize(W, H)
+    sums = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")     # accumulation buffer (float4 per pixel)
+    ctx.set_sum_buffer(sums.data_ptr())
+    ctx.set_frame(cam, clock, RECURSION, 1.0)
+
+    spp = args.spp_per_step
+
+    def step(i):
+        # SAMPLE indices of this rank: rank + world * k
+        ctx.trace(rank + world * (i * spp), spp, world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(args.steps + i)
+    barrier()
+    sums.zero_()
+    ctx.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if dist is not None:
+        dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    st = ctx.stats()
+    tot = torch.tensor([float(st["rays"]), float(st["shadow_probes"] + st["glossy_probes"]), dt],
+                       dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[2])
+    rays, probes = float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        img = sums.view(H, W, 4)[..., :3] / float(args.steps * spp * world)
+        finite = torch.isfinite(img).all(dim=2)
+        # the shader's sqrt(1 - cos^2) (raytracer.glsl:204) goes NaN when a rounded cosine exceeds 1; such
+        # samples poison their pixel in the reference too, and are reproduced here
+        nonfinite_pixels = int((~finite).sum().item())
+        mean = img[finite].mean().item()
+        # dominant kernel: the depth-0 closest-hit launches (one camera ray per pixel-sample)
+        ext_ms, ext_n = st["extend0_ms"], max(1, st["extend0_launches"])
+        flops = float(st["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
+        achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (paths x bounces) at 1080p",
+            "value": rays / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cubes 424 tris, 1920x1080, RECURSION 6, %d spp per GPU (%d spp/step), "
+                                   "constant environment, brute-force closest hit" % (args.steps * spp, spp),
+                       "pipeline": "staged" if args.pipeline else "single-kernel",
+                       "parallelism": "spp split x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
+            "seconds_to_%dspp" % (args.steps * spp): dt,
+            "probe_rays_per_s_M": probes / dt / 1e6,
+            "rays_per_pixel_sample": rays / max(1.0, float(st["pixel_samples"]) * world),
+            "mean_radiance": mean,
+            "nonfinite_pixels": nonfinite_pixels,
+            "roofline": {
+                "bound": "valu", "kernel": "k_extend<FIRST> (depth-0 brute-force closest hit + shading)",
+                "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_VALU_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": ext_ms / ext_n, "launches": int(st["extend0_launches"]),
+                "flops_per_launch": flops / ext_n,
+                "probe_kernels_ms": st["probe_ms"], "extend_kernels_ms": st["extend_ms"], "shade_kernels_ms": st["shade_ms"],
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, cam, clock)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,8 +24,9 @@ class RtStats(ctypes.Structure):
     _fields_ = [("pixel_samples", ctypes.c_uint64), ("rays", ctypes.c_uint64), ("shadow_probes", ctypes.c_uint64),
                 ("glossy_probes", ctypes.c_uint64), ("closest_tests", ctypes.c_uint64),
                 ("probe_tests", ctypes.c_uint64), ("trace_ms", ctypes.c_double), ("extend_ms", ctypes.c_double),
-                ("probe_ms", ctypes.c_double), ("extend_launches", ctypes.c_uint64),
-                ("probe_launches", ctypes.c_uint64)]
+                ("probe_ms", ctypes.c_double), ("shade_ms", ctypes.c_double), ("extend_launches", ctypes.c_uint64),
+                ("probe_launches", ctypes.c_uint64), ("extend0_ms", ctypes.c_double),
+                ("extend0_launches", ctypes.c_uint64)]
 
 
 class GpuRtError(RuntimeError):
@@ -35,7 +36,8 @@ class GpuRtError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libgpurt.so")
+    """Path of the HIP library; GPURT_LIB selects another build of it (used for A/B timing of variants)."""
+    return os.environ.get("GPURT_LIB") or os.path.join(_HERE, "libgpurt.so")
 
 
 _LIB = None

@@ -1,0 +1,16 @@
+// exr.hpp - minimal OpenEXR scanline reader/writer (the reference uses tinyexr's LoadEXR / SaveEXR,
+// Scene.cpp:81,110,504, which is not part of its repository).
+//   write: float32 channels, no compression, 3 (B,G,R) or 4 (A,B,G,R) channels
+//   read : scanline files, NONE / ZIPS / ZIP compression, HALF or FLOAT channels named R,G,B,(A);
+//          result is RGBA float32 (A = 1 when absent), row 0 = first scanline of the file
+#pragma once
+
+#include <string>
+#include <vector>
+
+namespace host {
+
+bool writeEXR(const std::string &path, int width, int height, int channels, const float *pixels, std::string *err);
+bool readEXR(const std::string &path, int &width, int &height, std::vector<float> &rgba, std::string *err);
+
+}  // namespace host

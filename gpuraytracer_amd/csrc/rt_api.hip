@@ -53,6 +53,7 @@ struct rt_context {
     int pipeline = 1;
     int batch_samples = 4;
     int profiling = 0;
+    int fuse_shade = 1;
 
     // stats
     DStats *d_stats = nullptr;
@@ -457,7 +458,7 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_samples, samples.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_light_seeds, seeds.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
-        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if (ctx->profiling && ctx->pipeline == 0) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (ctx->pipeline == 0) {
             const uint32_t tiles = ((ctx->width + 7u) >> 3) * ((ctx->height + 7u) >> 3);
             hipLaunchKernelGGL(k_trace_mega, dim3(tiles), dim3(64), 0, ctx->stream, sc, ctx->frame, ctx->d_sum,
@@ -467,17 +468,20 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
             const char *msg = nullptr;
             ctx->pipe.h_light_seeds.assign(seeds.begin(), seeds.begin() + n);
             hipError_t e = ctx->pipe.run(sc, ctx->frame, ctx->d_sum, ctx->d_samples, ctx->d_light_seeds, (int)n,
-                                         ctx->d_stats, ctx->stream, ctx->profiling != 0, &ctx->host_stats, &msg);
+                                         ctx->d_stats, ctx->stream, ctx->profiling != 0, ctx->fuse_shade != 0,
+                                         &ctx->host_stats, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
                             msg ? msg : "pipeline", hipGetErrorString(e));
         }
-        if (ctx->profiling) {
+        if (ctx->profiling && ctx->pipeline == 0) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
             HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
             float ms = 0.0f;
             HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
             ctx->host_stats.trace_ms += (double)ms;
+            ctx->host_stats.extend_ms += (double)ms;     // the single kernel holds every stage
+            ctx->host_stats.extend_launches++;
         }
         done += n;
     }
@@ -574,6 +578,11 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     if (!ctx || !out) return RT_ERR_INVALID;
     if (bind_device(ctx)) return RT_ERR_DEVICE;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        const double before = ctx->host_stats.extend_ms + ctx->host_stats.probe_ms + ctx->host_stats.shade_ms;
+        HIP_TRY(ctx, ctx->pipe.collect_times(&ctx->host_stats));
+        ctx->host_stats.trace_ms += ctx->host_stats.extend_ms + ctx->host_stats.probe_ms + ctx->host_stats.shade_ms - before;
+    }
     DStats ds;
     HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
     rt_stats s = ctx->host_stats;
@@ -593,6 +602,8 @@ int rt_reset_stats(rt_context *ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemset(ctx->d_stats, 0, sizeof(DStats)));
     memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
+    rt_stats scratch;
+    HIP_TRY(ctx, ctx->pipe.collect_times(&scratch));
     return RT_OK;
 }
 
@@ -604,6 +615,8 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "batch_samples")) {
         if (value < 1 || value > 64) return fail(ctx, RT_ERR_LIMIT, "batch_samples must be in [1, 64]");
         ctx->batch_samples = (int)value;
+    } else if (!strcmp(name, "fuse_shade")) {
+        ctx->fuse_shade = value ? 1 : 0;
     } else if (!strcmp(name, "profiling")) {
         ctx->profiling = value ? 1 : 0;
     } else {

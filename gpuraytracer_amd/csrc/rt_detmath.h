@@ -1,11 +1,13 @@
 // Deterministic elementary functions for the path tracer.
 //
-// Every function here is a fixed sequence of IEEE-754 binary32/binary64 additions,
-// subtractions, multiplications, divisions, correctly rounded float square roots,
-// comparisons and integer conversions.  Compiled with floating-point contraction
-// disabled (-ffp-contract=off) the sequence gives the same bits on an x86 host and
-// on a gfx950 device, which is what lets a CPU checker compare rendered images with
-// the device bit for bit.  Results are within one float ulp of the exact value.
+// Every function here is a fixed sequence of IEEE-754 binary32 additions, subtractions,
+// multiplications, divisions, correctly rounded square roots, floor, comparisons and
+// integer conversions.  Compiled with floating-point contraction disabled
+// (-ffp-contract=off) the sequence gives the same bits on an x86 host and on a gfx950
+// device, which is what lets a CPU checker compare rendered images with the device bit
+// for bit.  Results are within about 2 float ulps of the exact value on the ranges the
+// shader uses (tan: 4 ulps): polynomial kernels with the classic single-precision
+// coefficients, Cody-Waite argument reduction.
 //
 // The GLSL built-ins these stand in for (sin, cos, tan, asin, acos, atan) are used by
 // the reference shader at res/shader/raytracer.glsl:108-112 (randomSphere),
@@ -20,160 +22,131 @@
 
 namespace dm {
 
-constexpr double PIO2_HI = 1.57079632679489655800e+00;
-constexpr double PIO2_LO = 6.12323399573676603587e-17;
-constexpr double PI_D = 3.14159265358979311600e+00;
-constexpr double PIO4_D = 7.85398163397448278999e-01;
-constexpr double TWO_OVER_PI = 6.36619772367581382433e-01;
+constexpr float TWO_OVER_PI_F = 0.63661977236758134308f;
+// pi/2 split in three parts whose products with small integers are exact (Cody-Waite)
+constexpr float PIO2_1 = 1.5703125f;
+constexpr float PIO2_2 = 4.837512969970703125e-4f;
+constexpr float PIO2_3 = 7.54978995489188216e-8f;
+constexpr float PIO2_HI = 1.5707962513e+00f;
+constexpr float PIO2_LO = 7.5497894159e-08f;
+constexpr float PI_F = 3.14159274101257324f;
+constexpr float PIO4_F = 0.785398185253143310f;
 
-// floor() for |x| < 2^62 without calling a library routine.
-DM_HD long long floor_ll(double x) {
-    long long k = (long long)x;            // truncates toward zero
-    if ((double)k > x) k -= 1;
-    return k;
+// sin(r), cos(r) for |r| <= pi/4
+DM_HD float sin_kernel(float r) {
+    const float z = r * r;
+    const float p = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z;
+    return r + r * p;
+}
+DM_HD float cos_kernel(float r) {
+    const float z = r * r;
+    const float p = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * (z * z);
+    return (1.0f - 0.5f * z) + p;
 }
 
-// sin and cos of r, |r| <= pi/4, Taylor polynomials evaluated by Horner's rule in double.
-DM_HD double sin_kernel(double r) {
-    const double z = r * r;
-    double p = 1.0 / 6227020800.0;
-    p = p * z + (-1.0 / 39916800.0);
-    p = p * z + (1.0 / 362880.0);
-    p = p * z + (-1.0 / 5040.0);
-    p = p * z + (1.0 / 120.0);
-    p = p * z + (-1.0 / 6.0);
-    return r + (r * z) * p;
-}
-
-DM_HD double cos_kernel(double r) {
-    const double z = r * r;
-    double p = -1.0 / 87178291200.0;
-    p = p * z + (1.0 / 479001600.0);
-    p = p * z + (-1.0 / 3628800.0);
-    p = p * z + (1.0 / 40320.0);
-    p = p * z + (-1.0 / 720.0);
-    p = p * z + (1.0 / 24.0);
-    return (1.0 - 0.5 * z) + (z * z) * p;
-}
-
-// sin(x) and cos(x) in double for a float argument of moderate size (|x| < 1e6).
-DM_HD void sincos_d(float xf, double &s, double &c) {
-    const double x = (double)xf;
-    const long long k = floor_ll(x * TWO_OVER_PI + 0.5);
-    const double kd = (double)k;
-    const double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
-    const double sr = sin_kernel(r);
-    const double cr = cos_kernel(r);
-    switch ((int)(k & 3)) {
-        case 0: s = sr; c = cr; break;
-        case 1: s = cr; c = -sr; break;
-        case 2: s = -sr; c = -cr; break;
-        default: s = -cr; c = sr; break;
-    }
-}
-
+// sin(x) and cos(x); accurate for |x| up to a few hundred.
 DM_HD void sincos(float x, float &s, float &c) {
-    double sd, cd;
-    sincos_d(x, sd, cd);
-    s = (float)sd;
-    c = (float)cd;
+    const float kf = __builtin_floorf(x * TWO_OVER_PI_F + 0.5f);
+    const float r = ((x - kf * PIO2_1) - kf * PIO2_2) - kf * PIO2_3;
+    const float sr = sin_kernel(r);
+    const float cr = cos_kernel(r);
+    const int q = (int)kf & 3;
+    const float s0 = (q & 1) ? cr : sr;
+    const float c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
 }
 
 DM_HD float sin(float x) {
-    double sd, cd;
-    sincos_d(x, sd, cd);
-    return (float)sd;
+    float s, c;
+    sincos(x, s, c);
+    return s;
 }
-
 DM_HD float cos(float x) {
-    double sd, cd;
-    sincos_d(x, sd, cd);
-    return (float)cd;
+    float s, c;
+    sincos(x, s, c);
+    return c;
 }
-
 DM_HD float tan(float x) {
-    double sd, cd;
-    sincos_d(x, sd, cd);
-    return (float)(sd / cd);
+    float s, c;
+    sincos(x, s, c);
+    return s / c;
 }
 
-// Square root of a double in [0, 1]: float sqrt (correctly rounded) plus one Newton step.
-DM_HD double sqrt01_d(double z) {
-    const float s0f = __builtin_sqrtf((float)z);
-    if (s0f == 0.0f) return 0.0;
-    const double s0 = (double)s0f;
-    return s0 + (z - s0 * s0) / (2.0 * s0);
-}
-
-// x * R(x^2) term of asin on |x| <= 0.5 (rational approximation, fdlibm coefficients).
-DM_HD double asin_r(double z) {
-    const double p = z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 +
-                     z * (2.01212532134862925881e-01 + z * (-4.00555345006794114027e-02 +
-                     z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
-    const double q = 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 +
-                     z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+// Rational term of asin/acos: asin(x) = x + x*R(x^2) on |x| <= 0.5
+DM_HD float asin_r(float z) {
+    const float p = z * (1.6666586697e-01f + z * (-4.2743422091e-02f + z * -8.6563630030e-03f));
+    const float q = 1.0f + z * -7.0662963390e-01f;
     return p / q;
 }
 
-// asin for x in [-1, 1]; arguments outside are clamped to the interval.
-DM_HD double asin_d(float xf) {
-    double x = (double)xf;
-    if (x > 1.0) x = 1.0;
-    if (x < -1.0) x = -1.0;
-    const double ax = x < 0.0 ? -x : x;
-    if (ax < 0.5) return x + x * asin_r(x * x);
-    const double z = (1.0 - ax) * 0.5;
-    const double s = sqrt01_d(z);
-    const double r = (PIO2_HI - 2.0 * (s + s * asin_r(z))) + PIO2_LO;
-    return x < 0.0 ? -r : r;
-}
-
-DM_HD float asin(float x) { return (float)asin_d(x); }
-
 // acos for x in [-1, 1]; arguments outside are clamped to the interval.
-DM_HD float acos(float xf) {
-    double x = (double)xf;
-    if (x > 1.0) x = 1.0;
-    if (x < -1.0) x = -1.0;
-    const double ax = x < 0.0 ? -x : x;
-    if (ax < 0.5) return (float)((PIO2_HI - (x + x * asin_r(x * x))) + PIO2_LO);
-    const double z = (1.0 - ax) * 0.5;
-    const double s = sqrt01_d(z);
-    const double w = 2.0 * (s + s * asin_r(z));
-    return (float)(x < 0.0 ? (PI_D - w) : w);
+DM_HD float acos(float x) {
+    if (x > 1.0f) x = 1.0f;
+    if (x < -1.0f) x = -1.0f;
+    if (x > -0.5f && x < 0.5f) return PIO2_HI - (x - (PIO2_LO - x * asin_r(x * x)));
+    if (x <= -0.5f) {
+        const float z = (1.0f + x) * 0.5f;
+        const float s = __builtin_sqrtf(z);
+        const float w = asin_r(z) * s - PIO2_LO;
+        return 2.0f * (PIO2_HI - (s + w));
+    }
+    const float z = (1.0f - x) * 0.5f;
+    const float s = __builtin_sqrtf(z);
+    if (s == 0.0f) return 0.0f;
+    // df = s with the low 12 mantissa bits cleared, so that df*df is exact
+    unsigned int bits = __builtin_bit_cast(unsigned int, s) & 0xFFFFF000u;
+    const float df = __builtin_bit_cast(float, bits);
+    const float cc = (z - df * df) / (s + df);
+    const float w = asin_r(z) * s + cc;
+    return 2.0f * (df + w);
 }
 
-// atan(a) for a in [0, 1].
-DM_HD double atan01_d(double a) {
-    double base = 0.0;
-    double t = a;
-    if (a > 0.41421356237309503) {
-        t = (a - 1.0) / (a + 1.0);
-        base = PIO4_D;
+// asin for x in [-1, 1]; arguments outside are clamped to the interval.
+DM_HD float asin(float x) {
+    if (x > 1.0f) x = 1.0f;
+    if (x < -1.0f) x = -1.0f;
+    const float ax = x < 0.0f ? -x : x;
+    if (ax < 0.5f) return x + x * asin_r(x * x);
+    const float z = (1.0f - ax) * 0.5f;
+    const float s = __builtin_sqrtf(z);
+    float r;
+    if (s == 0.0f) {
+        r = PIO2_HI + PIO2_LO;
+    } else {
+        unsigned int bits = __builtin_bit_cast(unsigned int, s) & 0xFFFFF000u;
+        const float df = __builtin_bit_cast(float, bits);
+        const float cc = (z - df * df) / (s + df);
+        const float w = asin_r(z) * s + cc;
+        r = PIO2_HI - (2.0f * (df + w) - PIO2_LO);
     }
-    const double z = t * t;
-    // alternating series atan(t) = t + t*z*(-1/3 + z*(1/5 + z*(-1/7 + ...))), 20 terms
-    double p = 0.0;
-    for (int n = 20; n >= 1; --n) {
-        const double coef = 1.0 / (double)(2 * n + 1);
-        p = ((n & 1) ? -coef : coef) + z * p;
+    return x < 0.0f ? -r : r;
+}
+
+// atan(a) for a in [0, 1]
+DM_HD float atan01(float a) {
+    float base = 0.0f, t = a;
+    if (a > 0.4142135623730950f) {
+        t = (a - 1.0f) / (a + 1.0f);
+        base = PIO4_F;
     }
-    return base + (t + (t * z) * p);
+    const float z = t * t;
+    const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z;
+    return base + (t + t * p);
 }
 
 // atan2(y, x) with the usual quadrant rules; atan2(0, 0) = 0.
-DM_HD float atan2(float yf, float xf) {
-    const double x = (double)xf, y = (double)yf;
-    const double ax = x < 0.0 ? -x : x;
-    const double ay = y < 0.0 ? -y : y;
-    const double hi = ax > ay ? ax : ay;
-    const double lo = ax > ay ? ay : ax;
-    if (hi == 0.0) return 0.0f;
-    double r = atan01_d(lo / hi);
-    if (ay > ax) r = (PIO2_HI - r) + PIO2_LO;
-    if (x < 0.0) r = PI_D - r;
-    if (y < 0.0) r = -r;
-    return (float)r;
+DM_HD float atan2(float y, float x) {
+    const float ax = x < 0.0f ? -x : x;
+    const float ay = y < 0.0f ? -y : y;
+    const float hi = ax > ay ? ax : ay;
+    const float lo = ax > ay ? ay : ax;
+    if (hi == 0.0f) return 0.0f;
+    float r = atan01(lo / hi);
+    if (ay > ax) r = PIO2_HI - (r - PIO2_LO);
+    if (x < 0.0f) r = PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
 }
 
 }  // namespace dm

@@ -116,8 +116,15 @@ RT_DEV f3 random_sphere(uint32_t &seed) {          // :100-113
 
 struct Tri { f3 n, p, u, v; };
 
-RT_DEV Tri load_tri(const float4 *__restrict__ geo, int i) {
-    const float4 a = geo[3 * i + 0], b = geo[3 * i + 1], c = geo[3 * i + 2];
+// Triangle records never change while a kernel runs.  Reading them through the constant address
+// space tells the compiler so; with a wave-uniform index the loads then become scalar loads
+// (s_load_dwordx4/x8 into SGPRs) even in kernels that also store to global memory.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4f *const_v4f_ptr;
+
+RT_DEV Tri load_tri(const float4 *geo, int i) {
+    const const_v4f_ptr g = (const_v4f_ptr)geo;
+    const v4f a = g[3 * i + 0], b = g[3 * i + 1], c = g[3 * i + 2];
     Tri t;
     t.n = mk3(a.x, a.y, a.z);
     t.p = mk3(a.w, b.x, b.y);
@@ -133,34 +140,50 @@ RT_DEV Tri load_tri_checked(const DScene &sc, int i) {
     return t;
 }
 
-// Closest-hit test, raytracer.glsl:125-162.  `isec` = (x, y, relative_depth, determinant), all
-// still scaled by the determinant.  Returns true and overwrites isec when the triangle is
-// front-facing, in front of the origin, not farther than isec, and the point is inside.
+// Closest-hit test, raytracer.glsl:125-162, in two steps so that a wave can skip the second one
+// when no lane needs it.  `isec` = (x, y, relative_depth, determinant), all still scaled by the
+// determinant.
+//
+// Step 1: plane tests.  Returns true when the triangle is front-facing, in front of the origin and
+// its plane is not farther along the ray than the hit in isec.
+struct PlaneTest { float det, rd; f3 delta; };
+
+RT_DEV bool plane_test_closest(const Ray &ray, const Tri &t, const f4 &isec, PlaneTest &pt) {
+    pt.det = -dot(ray.d, t.n);
+    pt.delta = ray.o - t.p;
+    pt.rd = dot(t.n, pt.delta);
+    return !((pt.det <= 0.0f) | (pt.rd <= 0.0f) | ((isec.z >= 0.0f) & (pt.rd * isec.w > isec.z * pt.det)));
+}
+// Step 2: inside test in (u, v, ray) coordinates.  Returns true when the point lies in the triangle.
+RT_DEV bool inside_test(const Ray &ray, const Tri &t, const PlaneTest &pt, float &rx, float &ry) {
+    const f3 minor = cross(ray.d, pt.delta);
+    rx = -dot(minor, t.v);
+    ry = dot(minor, t.u);
+    return !((rx < 0.0f) | (ry < 0.0f) | (rx + ry > pt.det));
+}
+
 RT_DEV bool intersect_triangle(const Ray &ray, const Tri &t, f4 &isec) {
-    const float det = -dot(ray.d, t.n);
-    const f3 delta = ray.o - t.p;
-    const float rd = dot(t.n, delta);
-    const bool reject0 = (det <= 0.0f) | (rd <= 0.0f) | ((isec.z >= 0.0f) & (rd * isec.w > isec.z * det));
-    const f3 minor = cross(ray.d, delta);
-    const float rx = -dot(minor, t.v);
-    const float ry = dot(minor, t.u);
-    const bool reject1 = (rx < 0.0f) | (ry < 0.0f) | (rx + ry > det);
-    const bool hit = !(reject0 | reject1);
-    if (hit) { isec.x = rx; isec.y = ry; isec.z = rd; isec.w = det; }
+    PlaneTest pt;
+    const bool p = plane_test_closest(ray, t, isec, pt);
+    float rx, ry;
+    const bool hit = p & inside_test(ray, t, pt, rx, ry);
+    if (hit) { isec.x = rx; isec.y = ry; isec.z = pt.rd; isec.w = pt.det; }
     return hit;
 }
 
 // Occlusion test, raytracer.glsl:164-196: only triangles facing away from the origin occlude.
+RT_DEV bool plane_test_shadow(const Ray &ray, const Tri &t, float max_t, PlaneTest &pt) {
+    pt.det = dot(ray.d, t.n);
+    pt.delta = t.p - ray.o;
+    pt.rd = dot(t.n, pt.delta);
+    return !((pt.det <= 0.0f) | (pt.rd <= 0.0f) | (pt.rd > pt.det * max_t));
+}
+
 RT_DEV bool intersect_triangle_shadow(const Ray &ray, const Tri &t, float max_t) {
-    const float det = dot(ray.d, t.n);
-    const f3 delta = t.p - ray.o;
-    const float rd = dot(t.n, delta);
-    const bool reject0 = (det <= 0.0f) | (rd <= 0.0f) | (rd > det * max_t);
-    const f3 minor = cross(ray.d, delta);
-    const float rx = -dot(minor, t.v);
-    const float ry = dot(minor, t.u);
-    const bool reject1 = (rx < 0.0f) | (ry < 0.0f) | (rx + ry > det);
-    return !(reject0 | reject1);
+    PlaneTest pt;
+    const bool p = plane_test_shadow(ray, t, max_t, pt);
+    float rx, ry;
+    return p & inside_test(ray, t, pt, rx, ry);
 }
 
 // ---------------------------------------------------------------- shading records

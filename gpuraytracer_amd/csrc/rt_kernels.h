@@ -22,33 +22,78 @@ RT_DEV unsigned long long wave_sum_u32(uint32_t v) {
 
 // ---------------------------------------------------------------- brute-force loops
 
+// In all three loops the plane tests of a triangle run for the whole wave; the costlier inside
+// test runs only if at least one lane passed them (a ballot), which is rare for the coherent rays
+// of a camera tile.  Skipping it for a wave changes nothing: a lane that fails the plane tests never
+// updates its state.  The any-hit loops look for "no lane
+// left" only once per block of BF_BLOCK triangles, which keeps the inner loop free of exits.
+
+constexpr int BF_BLOCK = 16;
+
 // findIntersection, raytracer.glsl:217-235.  Returns the triangle id (-1 = miss); isec as left
 // by the fold (x, y, relative_depth, determinant).
-RT_DEV int closest_hit_bf(const DScene &sc, const Ray &ray, f4 &isec) {
-    int best = -1;
-    isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 1.0f;
-    const float4 *__restrict__ geo = sc.geo;
-    const int count = sc.count;
-    for (int i = 0; i < count; i++) {
+RT_DEV int closest_hit_range(const float4 *geo, int begin, int end, const Ray &ray, bool active, int current,
+                             f4 &isec, int best) {
+    for (int i = begin; i < end; i++) {
         const Tri t = load_tri(geo, i);
-        if (intersect_triangle(ray, t, isec)) best = i;
+        PlaneTest pt;
+        const bool p = active & plane_test_closest(ray, t, isec, pt) & (i != current);
+        if (__builtin_amdgcn_ballot_w64(p) != 0ull) {
+            float rx, ry;
+            if (p & inside_test(ray, t, pt, rx, ry)) {
+                isec.x = rx; isec.y = ry; isec.z = pt.rd; isec.w = pt.det;
+                best = i;
+            }
+        }
     }
     return best;
 }
 
+RT_DEV int closest_hit_bf(const DScene &sc, const Ray &ray, f4 &isec) {
+    isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 1.0f;
+    return closest_hit_range(sc.geo, 0, sc.count, ray, true, -1, isec, -1);
+}
+
 // Occlusion loop of sampleLight, raytracer.glsl:372-378.  `active` lanes run the loop; returns
-// true for lanes whose probe ray is blocked.  The loop ends as soon as no lane needs it.
+// true for lanes whose probe ray is blocked.
 RT_DEV bool shadow_any_hit_bf(const DScene &sc, const Ray &ray, float max_t, int current, bool active) {
-    bool blocked = false;
-    const float4 *__restrict__ geo = sc.geo;
+    bool open = active;          // lane still looking for an occluder
     const int count = sc.count;
-    for (int i = 0; i < count; i++) {
-        if (__builtin_amdgcn_ballot_w64(active && !blocked) == 0ull) break;
-        const Tri t = load_tri(geo, i);
-        const bool h = intersect_triangle_shadow(ray, t, max_t);
-        if (active && h && (i != current)) blocked = true;
+    for (int i0 = 0; i0 < count; i0 += BF_BLOCK) {
+        if (__builtin_amdgcn_ballot_w64(open) == 0ull) break;
+        const int i1 = (i0 + BF_BLOCK < count) ? i0 + BF_BLOCK : count;
+        for (int i = i0; i < i1; i++) {
+            const Tri t = load_tri(sc.geo, i);
+            PlaneTest pt;
+            const bool p = open & plane_test_shadow(ray, t, max_t, pt) & (i != current);
+            if (__builtin_amdgcn_ballot_w64(p) != 0ull) {
+                float rx, ry;
+                open = open & !(p & inside_test(ray, t, pt, rx, ry));
+            }
+        }
     }
-    return blocked;
+    return active & !open;
+}
+
+// Any-hit of the closest-hit test against a fixed state `isec` over triangles [begin, end):
+// true for lanes where some triangle != current passes (second phase of sampleLightGlossy).
+RT_DEV bool closer_any_hit_range(const float4 *geo, int begin, int end, const Ray &ray, const f4 &isec, int current,
+                                 bool active) {
+    bool open = active;
+    for (int i0 = begin; i0 < end; i0 += BF_BLOCK) {
+        if (__builtin_amdgcn_ballot_w64(open) == 0ull) break;
+        const int i1 = (i0 + BF_BLOCK < end) ? i0 + BF_BLOCK : end;
+        for (int i = i0; i < i1; i++) {
+            const Tri t = load_tri(geo, i);
+            PlaneTest pt;
+            const bool p = open & plane_test_closest(ray, t, isec, pt) & (i != current);
+            if (__builtin_amdgcn_ballot_w64(p) != 0ull) {
+                float rx, ry;
+                open = open & !(p & inside_test(ray, t, pt, rx, ry));
+            }
+        }
+    }
+    return active & !open;
 }
 
 // Search loop of sampleLightGlossy, raytracer.glsl:403-419, in its two-phase form: triangles
@@ -57,23 +102,9 @@ RT_DEV bool shadow_any_hit_bf(const DScene &sc, const Ray &ray, float max_t, int
 // 2 light `light_id` visible with `isec`.
 RT_DEV int glossy_search_bf(const DScene &sc, const Ray &ray, int current, bool active, int &light_id, f4 &isec) {
     isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
-    light_id = -1;
-    const float4 *__restrict__ geo = sc.geo;
     const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
-    for (int i = 0; i < lights; i++) {
-        const Tri t = load_tri(geo, i);
-        f4 trial = isec;
-        const bool h = intersect_triangle(ray, t, trial);
-        if (active && h && (i != current)) { isec = trial; light_id = i; }
-    }
-    bool blocked = false;
-    for (int i = lights; i < count; i++) {
-        if (__builtin_amdgcn_ballot_w64(active && !blocked) == 0ull) break;
-        const Tri t = load_tri(geo, i);
-        f4 trial = isec;
-        const bool h = intersect_triangle(ray, t, trial);
-        if (active && h && (i != current)) blocked = true;
-    }
+    light_id = closest_hit_range(sc.geo, 0, lights, ray, active, current, isec, -1);
+    const bool blocked = closer_any_hit_range(sc.geo, lights, count, ray, isec, current, active);
     if (blocked) return 0;
     return light_id < 0 ? 1 : 2;
 }

@@ -21,6 +21,7 @@
 //   s0 = (o.xyz, d.x)  s1 = (d.yz, path.xy)  s2 = (path.z, energy.xyz)
 //   s3 = (seed, current triangle)            written by extend, read by the probe stages
 //   p0 = (probe_d.xyz, max_t)  p1 = (c.xyz, w)   (see struct Bounce)
+//   h0 = (u, v, t, hit triangle id)          written by extend, read by shade
 // Path id = slot * paths_per_sample + tile * 64 + lane, where `slot` is the sample's position in
 // the batch and (tile, lane) is the 8x8 pixel tile and the pixel inside it, so that the depth-0
 // wave holds the same 64 pixels as a reference workgroup.
@@ -34,7 +35,7 @@
 namespace rt {
 
 struct PipeBuffers {
-    float4 *s0, *s1, *s2, *p0, *p1;
+    float4 *s0, *s1, *s2, *p0, *p1, *h0;
     uint2 *s3;
     uint32_t *q_ext[2];
     uint32_t *q_shadow, *q_glossy;
@@ -70,19 +71,53 @@ RT_DEV void queue_push(uint32_t *__restrict__ queue, uint32_t *__restrict__ coun
     if (pred) queue[base + lane_rank] = id;
 }
 
-// Extend stage.  FIRST: depth 0, the wave generates the camera rays of its 64 pixels itself
-// (raytracer.glsl:586-607) instead of reading a queue.
-template <bool FIRST>
+// Shading of one path after its closest hit is known (raytracer.glsl:452-556): adds the sky on a
+// miss, otherwise runs shade_pre and routes the path to the shadow queue, the glossy queue or (no
+// probe needed) through shade_post to the next extend queue.  Called by whole waves; `live` masks lanes.
+RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffers &b, int depth, int q_in,
+                            const uint32_t *__restrict__ coins, uint32_t paths_per_sample, int max_depth, bool live,
+                            uint32_t id, PathState &ps, int hit, float hu, float hv, float ht) {
+    uint32_t *cnt = b.counters + 4 * depth;
+    uint32_t *cnt_next = b.counters + 4 * (depth + 1);
+    bool to_shadow = false, to_glossy = false, to_next = false;
+    if (live) {
+        if (hit < 0) {
+            ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
+        } else {
+            const uint32_t slot = id / paths_per_sample;
+            const bool coin_diffuse = coins[slot * (uint32_t)max_depth + (uint32_t)depth] != 0u;
+            Bounce bn;
+            shade_pre(sc, fr, ps, hit, hu, hv, ht, coin_diffuse, bn);
+            if (bn.kind == PROBE_NONE) {
+                to_next = shade_post(sc, ps, hit, false, mk3(0.0f, 0.0f, 0.0f));
+            } else {
+                b.p0[id] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
+                b.p1[id] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
+                to_shadow = bn.kind == PROBE_SHADOW;
+                to_glossy = bn.kind == PROBE_GLOSSY;
+            }
+            b.s3[id] = make_uint2(ps.seed, (uint32_t)hit);
+        }
+        store_path(b, id, ps);
+    }
+    to_next = to_next && (depth + 1 < max_depth);
+    queue_push(b.q_shadow, cnt + 1, to_shadow, id);
+    queue_push(b.q_glossy, cnt + 2, to_glossy, id);
+    queue_push(b.q_ext[q_in ^ 1], cnt_next + 0, to_next, id);
+}
+
+// Extend stage: the closest-hit loop.  FIRST: depth 0, the wave generates the camera rays of its 64
+// pixels itself (raytracer.glsl:586-607) instead of reading a queue.  FUSED: the wave goes on to
+// shade its paths; otherwise it writes the hit record h0 = (u, v, t, triangle id; -1 = miss) and
+// k_shade does the shading, which lets this kernel run with a small register footprint.
+template <bool FIRST, bool FUSED>
 __global__ __launch_bounds__(64) void k_extend(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
                                                const uint32_t *__restrict__ samples,
                                                const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
                                                uint32_t n_slots, int max_depth, DStats *__restrict__ stats) {
     const uint32_t lane = threadIdx.x;
-    uint32_t *cnt = b.counters + 4 * depth;
-    uint32_t *cnt_next = b.counters + 4 * (depth + 1);
-    const uint32_t total = FIRST ? paths_per_sample * n_slots : cnt[0];
+    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.counters[4 * depth];
     const uint32_t *__restrict__ q = b.q_ext[q_in];
-    uint32_t *q_next = b.q_ext[q_in ^ 1];
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
     uint32_t n_paths = 0;
 
@@ -91,64 +126,84 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DFrame fr, PipeBuffers
         bool live = qi < total;
         uint32_t id = 0;
         PathState ps;
-        uint32_t slot;
         if (FIRST) {
             id = qi;
-            slot = live ? id / paths_per_sample : 0u;
+            const uint32_t slot = live ? id / paths_per_sample : 0u;
             const uint32_t local = id - slot * paths_per_sample;
             const uint32_t tile = local >> 6;
             const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
             const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
-            live = live && (tx < fr.width) && (ty < fr.height);
+            const bool in_image = (tx < fr.width) && (ty < fr.height);
             ps.seed = pixel_seed(fr, tx, ty, samples[slot]);
             const Ray cam = camera_ray(fr, tx, ty, ps.seed);
             ps.o = cam.o; ps.d = cam.d;
             ps.path = mk3(1.0f, 1.0f, 1.0f);
             ps.energy = mk3(0.0f, 0.0f, 0.0f);
+            if (live && (!FUSED || !in_image)) {     // padding lanes of ragged tiles too: their energy stays 0
+                store_path(b, id, ps);
+                b.s3[id] = make_uint2(ps.seed, 0u);
+            }
+            live = live && in_image;
             n_paths += live ? 1u : 0u;
-            if (!live && qi < total) store_path(b, id, ps);   // padding lanes: energy 0, never read back
         } else {
             id = live ? q[qi] : 0u;
-            load_path(b, id, ps);
-            ps.seed = b.s3[id].x;
-            slot = id / paths_per_sample;
+            if (FUSED) {
+                load_path(b, id, ps);
+                ps.seed = b.s3[id].x;
+            } else {
+                const float4 a = b.s0[id], c = b.s1[id];
+                ps.o = mk3(a.x, a.y, a.z);
+                ps.d = mk3(a.w, c.x, c.y);
+            }
         }
-
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
         const int hit = closest_hit_bf(sc, ray, isec);
-
-        bool to_shadow = false, to_glossy = false, to_next = false;
-        if (live) {
-            if (hit < 0) {
-                ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
-            } else {
-                const bool coin_diffuse = coins[slot * (uint32_t)max_depth + (uint32_t)depth] != 0u;
-                const float inv_det = 1.0f / isec.w;
-                Bounce bn;
-                shade_pre(sc, fr, ps, hit, isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, coin_diffuse, bn);
-                if (bn.kind == PROBE_NONE) {
-                    to_next = shade_post(sc, ps, hit, false, mk3(0.0f, 0.0f, 0.0f));
-                } else {
-                    b.p0[id] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
-                    b.p1[id] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
-                    to_shadow = bn.kind == PROBE_SHADOW;
-                    to_glossy = bn.kind == PROBE_GLOSSY;
-                }
-                b.s3[id] = make_uint2(ps.seed, (uint32_t)hit);
-            }
-            store_path(b, id, ps);
+        const float inv_det = 1.0f / isec.w;
+        if (FUSED) {
+            shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, hit,
+                            isec.x * inv_det, isec.y * inv_det, isec.z * inv_det);
+        } else if (live) {
+            b.h0[id] = make_float4(isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, __int_as_float(hit));
         }
-        to_next = to_next && (depth + 1 < max_depth);
-        queue_push(b.q_shadow, cnt + 1, to_shadow, id);
-        queue_push(b.q_glossy, cnt + 2, to_glossy, id);
-        queue_push(q_next, cnt_next + 0, to_next, id);
     }
     if (FIRST) {
         const unsigned long long p = wave_sum_u32(n_paths);
         if (lane == 0 && p) { atomicAdd(&stats->pixel_samples, p); atomicAdd(&stats->rays, p); }
     } else if (blockIdx.x == 0 && lane == 0) {
         atomicAdd(&stats->rays, (unsigned long long)total);
+    }
+}
+
+// Shade stage of the unfused form.
+template <bool FIRST>
+__global__ __launch_bounds__(64) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
+                                              const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
+                                              uint32_t n_slots, int max_depth) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.counters[4 * depth];
+    const uint32_t *__restrict__ q = b.q_ext[q_in];
+    const uint32_t tiles_x = (fr.width + 7u) >> 3;
+
+    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+        const uint32_t qi = base + lane;
+        bool live = qi < total;
+        uint32_t id = 0;
+        if (FIRST) {
+            id = live ? qi : 0u;
+            const uint32_t tile = (id % paths_per_sample) >> 6;
+            const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
+            const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
+            live = live && (tx < fr.width) && (ty < fr.height);
+        } else {
+            id = live ? q[qi] : 0u;
+        }
+        PathState ps;
+        load_path(b, id, ps);
+        ps.seed = b.s3[id].x;
+        const float4 h = b.h0[id];
+        shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, __float_as_int(h.w),
+                        h.x, h.y, h.z);
     }
 }
 
@@ -254,11 +309,15 @@ struct Pipeline {
     uint32_t *d_coins = nullptr;
     size_t cap_coins = 0;
     uint32_t *h_count = nullptr;   // pinned, for the early-stop read-back
+    // Profiling: events are recorded around every stage launch and turned into times lazily
+    // (collect_times), so that the timed region carries no extra synchronisation.
     std::vector<hipEvent_t> events;
+    std::vector<int> kinds;        // interval i = [event i, event i+1]: 0 extend, 3 extend at depth 0, 1 probes, 2 shade, -1 not counted
+    size_t ev_used = 0;
 
     void release() {
         (void)hipFree(buf.s0); (void)hipFree(buf.s1); (void)hipFree(buf.s2); (void)hipFree(buf.s3);
-        (void)hipFree(buf.p0); (void)hipFree(buf.p1);
+        (void)hipFree(buf.p0); (void)hipFree(buf.p1); (void)hipFree(buf.h0);
         (void)hipFree(buf.q_ext[0]); (void)hipFree(buf.q_ext[1]); (void)hipFree(buf.q_shadow); (void)hipFree(buf.q_glossy);
         (void)hipFree(buf.counters);
         (void)hipFree(d_coins);
@@ -276,9 +335,9 @@ struct Pipeline {
 #define PIPE_ALLOC(ptr, bytes) do { *what = #ptr; e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
         if (paths > cap_paths) {
             (void)hipFree(buf.s0); (void)hipFree(buf.s1); (void)hipFree(buf.s2); (void)hipFree(buf.s3);
-            (void)hipFree(buf.p0); (void)hipFree(buf.p1);
+            (void)hipFree(buf.p0); (void)hipFree(buf.p1); (void)hipFree(buf.h0);
             (void)hipFree(buf.q_ext[0]); (void)hipFree(buf.q_ext[1]); (void)hipFree(buf.q_shadow); (void)hipFree(buf.q_glossy);
-            buf.s0 = buf.s1 = buf.s2 = buf.p0 = buf.p1 = nullptr; buf.s3 = nullptr;
+            buf.s0 = buf.s1 = buf.s2 = buf.p0 = buf.p1 = buf.h0 = nullptr; buf.s3 = nullptr;
             buf.q_ext[0] = buf.q_ext[1] = buf.q_shadow = buf.q_glossy = nullptr;
             cap_paths = 0;
             PIPE_ALLOC(buf.s0, sizeof(float4) * paths);
@@ -287,6 +346,7 @@ struct Pipeline {
             PIPE_ALLOC(buf.s3, sizeof(uint2) * paths);
             PIPE_ALLOC(buf.p0, sizeof(float4) * paths);
             PIPE_ALLOC(buf.p1, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.h0, sizeof(float4) * paths);
             PIPE_ALLOC(buf.q_ext[0], sizeof(uint32_t) * paths);
             PIPE_ALLOC(buf.q_ext[1], sizeof(uint32_t) * paths);
             PIPE_ALLOC(buf.q_shadow, sizeof(uint32_t) * paths);
@@ -319,7 +379,28 @@ struct Pipeline {
     // Renders the `n` samples listed in d_samples (light seeds in h_light_seeds order) and adds them to `sum`.
     hipError_t run(const DScene &sc, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
                    const uint32_t *d_light_seeds, int n, DStats *d_stats, hipStream_t stream, bool profiling,
-                   rt_stats *host_stats, const char **what);
+                   bool fused, rt_stats *host_stats, const char **what);
+
+    // Adds the time of every recorded interval to host_stats and recycles the events.
+    hipError_t collect_times(rt_stats *host_stats) {
+        hipError_t e = hipSuccess;
+        if (ev_used >= 2) {
+            e = hipEventSynchronize(events[ev_used - 1]);
+            for (size_t i = 0; e == hipSuccess && i + 1 < ev_used; i++) {
+                if (kinds[i] < 0) continue;
+                float ms = 0.0f;
+                e = hipEventElapsedTime(&ms, events[i], events[i + 1]);
+                if (e != hipSuccess) break;
+                if (kinds[i] == 0 || kinds[i] == 3) { host_stats->extend_ms += ms; host_stats->extend_launches++; }
+                if (kinds[i] == 3) { host_stats->extend0_ms += ms; host_stats->extend0_launches++; }
+                else if (kinds[i] == 2) { host_stats->shade_ms += ms; }
+                else { host_stats->probe_ms += ms; host_stats->probe_launches += 2; }
+            }
+        }
+        ev_used = 0;
+        kinds.clear();
+        return e;
+    }
 
     // light seeds are also needed on the host to tabulate the per-depth coin; set before run()
     std::vector<uint32_t> h_light_seeds;
@@ -327,7 +408,7 @@ struct Pipeline {
 
 inline hipError_t Pipeline::run(const DScene &sc, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
                                 const uint32_t *d_light_seeds, int n, DStats *d_stats, hipStream_t stream,
-                                bool profiling, rt_stats *host_stats, const char **what) {
+                                bool profiling, bool fused, rt_stats *host_stats, const char **what) {
     (void)d_light_seeds;
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
     const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
@@ -353,8 +434,8 @@ inline hipError_t Pipeline::run(const DScene &sc, const DFrame &fr, float4 *sum,
     PIPE_TRY(hipStreamSynchronize(stream));   // `coins` is a local
     PIPE_TRY(hipMemsetAsync(buf.counters, 0, sizeof(uint32_t) * 4 * (size_t)(max_depth + 2), stream));
 
-    size_t ev_used = 0;
-    auto stamp = [&]() -> hipError_t {
+    if (profiling && ev_used > 8192) PIPE_TRY(collect_times(host_stats));
+    auto stamp = [&](int kind_of_next_interval) -> hipError_t {
         if (!profiling) return hipSuccess;
         if (ev_used == events.size()) {
             hipEvent_t ev;
@@ -362,29 +443,46 @@ inline hipError_t Pipeline::run(const DScene &sc, const DFrame &fr, float4 *sum,
             if (ee != hipSuccess) return ee;
             events.push_back(ev);
         }
+        kinds.push_back(kind_of_next_interval);
         return hipEventRecord(events[ev_used++], stream);
     };
-    std::vector<int> kinds;   // per event interval: 0 extend, 1 probe
 
     const uint32_t chunks0 = (uint32_t)((paths + 63) / 64);
     const dim3 grid0(chunks0 < (uint32_t)PIPE_WAVES ? chunks0 : (uint32_t)PIPE_WAVES), grid(PIPE_WAVES), block(64);
     int q_in = 0;
     for (int depth = 0; depth < max_depth; depth++) {
-        PIPE_TRY(stamp());
-        if (depth == 0)
-            hipLaunchKernelGGL(k_extend<true>, grid0, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins, pps,
-                               (uint32_t)n, max_depth, d_stats);
-        else
-            hipLaunchKernelGGL(k_extend<false>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins, pps,
-                               (uint32_t)n, max_depth, d_stats);
-        PIPE_TRY(hipGetLastError());
-        PIPE_TRY(stamp());
+        PIPE_TRY(stamp(depth == 0 ? 3 : 0));
+        if (fused) {
+            if (depth == 0)
+                hipLaunchKernelGGL((k_extend<true, true>), grid0, block, 0, stream, sc, fr, buf, depth, q_in, d_samples,
+                                   d_coins, pps, (uint32_t)n, max_depth, d_stats);
+            else
+                hipLaunchKernelGGL((k_extend<false, true>), grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples,
+                                   d_coins, pps, (uint32_t)n, max_depth, d_stats);
+            PIPE_TRY(hipGetLastError());
+        } else {
+            if (depth == 0)
+                hipLaunchKernelGGL((k_extend<true, false>), grid0, block, 0, stream, sc, fr, buf, depth, q_in, d_samples,
+                                   d_coins, pps, (uint32_t)n, max_depth, d_stats);
+            else
+                hipLaunchKernelGGL((k_extend<false, false>), grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples,
+                                   d_coins, pps, (uint32_t)n, max_depth, d_stats);
+            PIPE_TRY(hipGetLastError());
+            PIPE_TRY(stamp(2));
+            if (depth == 0)
+                hipLaunchKernelGGL(k_shade<true>, grid0, block, 0, stream, sc, fr, buf, depth, q_in, d_coins, pps,
+                                   (uint32_t)n, max_depth);
+            else
+                hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_coins, pps,
+                                   (uint32_t)n, max_depth);
+            PIPE_TRY(hipGetLastError());
+        }
+        PIPE_TRY(stamp(1));
         hipLaunchKernelGGL(k_probe_shadow, grid, block, 0, stream, sc, buf, depth, q_in, max_depth, d_stats);
         PIPE_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_probe_glossy, grid, block, 0, stream, sc, fr, buf, depth, q_in, max_depth, d_stats);
         PIPE_TRY(hipGetLastError());
-        PIPE_TRY(stamp());
-        if (profiling) { kinds.push_back(0); kinds.push_back(1); kinds.push_back(-1); }
+        PIPE_TRY(stamp(-1));
         q_in ^= 1;
         // deep paths are rare: from depth 4 on, stop as soon as the next extend queue is empty
         if (depth >= 3 && depth + 1 < max_depth) {
@@ -397,16 +495,6 @@ inline hipError_t Pipeline::run(const DScene &sc, const DFrame &fr, float4 *sum,
                        fr.height, pps, (uint32_t)n);
     PIPE_TRY(hipGetLastError());
 
-    if (profiling && ev_used >= 2) {
-        PIPE_TRY(hipEventSynchronize(events[ev_used - 1]));
-        for (size_t i = 0; i + 1 < ev_used; i++) {
-            if (kinds[i] < 0) continue;
-            float ms = 0.0f;
-            PIPE_TRY(hipEventElapsedTime(&ms, events[i], events[i + 1]));
-            if (kinds[i] == 0) { host_stats->extend_ms += ms; host_stats->extend_launches++; }
-            else { host_stats->probe_ms += ms; host_stats->probe_launches += 2; }
-        }
-    }
 #undef PIPE_TRY
     return hipSuccess;
 }

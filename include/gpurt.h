@@ -70,8 +70,11 @@ typedef struct rt_stats {
     double   trace_ms;          /* device time of all rt_trace kernels (HIP events on the context stream) */
     double   extend_ms;         /* part of trace_ms spent in closest-hit kernels */
     double   probe_ms;          /* part of trace_ms spent in light-probe kernels */
+    double   shade_ms;          /* part of trace_ms spent in shading kernels */
     uint64_t extend_launches;
     uint64_t probe_launches;
+    double   extend0_ms;        /* part of extend_ms spent in the depth-0 (camera ray) closest-hit launches */
+    uint64_t extend0_launches;
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -160,6 +163,7 @@ int rt_reset_stats(rt_context *ctx);
  *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
  *                   1 = staged kernels over compacted ray queues (default)
  *   "batch_samples" samples rendered per pass of the staged pipeline (default 4)
+ *   "fuse_shade"    1 = the closest-hit kernel also shades its paths (default), 0 = separate shade kernel
  *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
 int rt_set_option(rt_context *ctx, const char *name, int64_t value);
 

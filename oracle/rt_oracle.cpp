@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -551,6 +552,12 @@ V3 trace(const Scene &sc, const Frame &fr, Ray ray, uint32_t seed, uint32_t ligh
         const V3 global_light = ((albedo * diff_light) * roughness + (specular * spec_light) * sw) * 2.0f;   // :557
 
         if (has_light) energy = energy + path * global_light;
+        if (getenv("ORC_DEBUG"))
+            fprintf(stderr, "depth %d tri %d mat %u sec %g %g %g N %g %g %g rough %g fres %g path %g %g %g dir %g %g %g "
+                    "has_light %d gl %g %g %g energy %g %g %g\n", depth, current_tri, mat_id, sec.x, sec.y, sec.z,
+                    normal.x, normal.y, normal.z, roughness, fresnel_reflectance, path.x, path.y, path.z,
+                    ray.direction.x, ray.direction.y, ray.direction.z, (int)has_light, global_light.x, global_light.y,
+                    global_light.z, energy.x, energy.y, energy.z);
 
         const V3 true_normal = v3(sc.models[current_tri].n);                                // :568-571
         if (dot(ray.direction, true_normal) <= 0.0f) break;

@@ -1,0 +1,62 @@
+"""The N > 1 path on CPU: two gloo ranks split the SAMPLE indices, each renders its share (the CPU
+checker stands in for the GPU renderer here, the product has no CPU path), and one reduce adds the
+per-rank sums onto rank 0."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import constant_env, load_scene
+from gpuraytracer_amd.camera import camera_matrix, DEFAULT_CLOCK
+from gpuraytracer_amd.distributed import mean_image, reduce_sums, shard_samples
+
+W, H, SPP = 24, 16, 7
+
+
+def test_shard_samples_partition():
+    for world in (1, 2, 3, 4, 8):
+        for total in (0, 1, 5, 8, 1024, 4096):
+            seen = []
+            for rank in range(world):
+                begin, count, stride = shard_samples(total, rank, world)
+                seen += [begin + k * stride for k in range(count)]
+            assert sorted(seen) == list(range(total))
+    with pytest.raises(ValueError):
+        shard_samples(4, 2, 2)
+
+
+def _worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = load_scene("cubes")
+    sc = oracle.OracleScene(*scene)
+    sc.upload_env(constant_env())
+    begin, count, stride = shard_samples(SPP, rank, world)
+    rgb, _ = sc.render(camera_matrix(), DEFAULT_CLOCK, 6, 1.0, W, H, begin, count, stride)
+    sums = torch.zeros(H * W * 4, dtype=torch.float32)
+    sums.view(H, W, 4)[..., :3] = torch.from_numpy(rgb)
+    reduce_sums(sums, dst=0)
+    if rank == 0:
+        np.save(out_path, sums.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_split_and_reduce(tmp_path, oracle_mod):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sum.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = mean_image(np.load(out), SPP, W, H)
+    sc = oracle_mod.OracleScene(*load_scene("cubes"))
+    sc.upload_env(constant_env())
+    want, _ = sc.render(camera_matrix(), DEFAULT_CLOCK, 6, 1.0, W, H, 0, SPP)
+    # same samples, different association of the float sum
+    assert np.allclose(got, want / SPP, rtol=1e-5, atol=1e-6)

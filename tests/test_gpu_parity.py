@@ -22,6 +22,9 @@ def _upload(ctx, scene, env):
 
 
 def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM):
+    # pipeline 0 = single kernel, 1 = staged with fused shading, 2 = staged with a separate shade kernel
+    ctx.set_option("fuse_shade", 0 if pipeline == 2 else 1)
+    pipeline = min(pipeline, 1)
     ctx.set_option("pipeline", pipeline)
     ctx.set_option("batch_samples", batch)
     ctx.resize(w, h)
@@ -65,7 +68,7 @@ def test_closest_hit_edge_cases(gpu_ctx, oracle_mod, cubes):
     assert ids[1] == len(cubes[0]) - 1          # an all-NaN ray passes every rejection: last triangle wins
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
     _upload(gpu_ctx, cubes, constant_env())
     for spp in (1, 4, 16):
@@ -75,7 +78,7 @@ def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
         assert [st["pixel_samples"], st["rays"], st["shadow_probes"], st["glossy_probes"]] == g["stats"].tolist()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
 def test_image_vs_checker_gradient_env_ragged(gpu_ctx, oracle_mod, cubes, pipeline):
     # 52 x 37 is not a multiple of the 8 x 8 tile; the gradient environment exercises the bilinear lookup
     _upload(gpu_ctx, cubes, gradient_env())
@@ -101,7 +104,7 @@ def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
     sc.upload_env(gradient_env())
     cam = camera_matrix((0.0, 1.0, -2.0), (-0.3, 0.0))
     want, wst = sc.render(cam, DEFAULT_CLOCK, 16, 1.0, 32, 24, 0, 3)
-    for pipeline in (0, 1):
+    for pipeline in (0, 1, 2):
         img, st = _render(gpu_ctx, 32, 24, 0, 3, recursion=16, pipeline=pipeline, batch=2, cam=cam)
         assert np.array_equal(img, want, equal_nan=True), pipeline
         assert st["rays"] == wst["rays"] and st["glossy_probes"] == wst["glossy_probes"]
@@ -166,7 +169,7 @@ def test_textured_materials_bit_exact(gpu_ctx, oracle_mod, cubes):
         target.upload_atlas_layer(2, 2, arm)
         target.set_has_texture(np.array([0, 0, 1, 0], np.int32))
     want, wst = sc.render(CAM, 4242, 6, 1.0, 48, 32, 0, 4)
-    for pipeline in (0, 1):
+    for pipeline in (0, 1, 2):
         img, st = _render(gpu_ctx, 48, 32, 0, 4, clock=4242, pipeline=pipeline)
         assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
         assert st["rays"] == wst["rays"]

@@ -1,0 +1,185 @@
+"""CPU tests of the C++ host layer (csrc/host/): Wavefront ingest against the numpy restatement,
+EXR reader/writer, camera matrix."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from gpuraytracer_amd import host
+from gpuraytracer_amd.camera import camera_matrix
+from oracle import scene_np
+
+OBJ = """# test scene
+mtllib t.mtl
+o Lamp
+v 0.0 2.0 0.0
+v 1.0 2.0 0.0
+v 0.0 2.0 1.0
+vt 0.0 0.0
+vt 1.0 0.0
+vt 0.0 1.0
+vn 0.0 -1.0 0.0
+usemtl Wall
+usemtl Light
+s off
+f 1/1/1 2/2/1 3/3/1
+o Floor
+v -4.0 0.0 -4.0
+v 4.0 0.0 -4.0
+v 4.0 0.0 4.0
+v -4.0 0.0 4.0
+v 0.5 0.5 0.5
+vt 0.25 0.75
+vn 0.0 1.0 0.0
+vn 0.577350 0.577350 0.577350
+usemtl Wall
+f 4/1/2 6/3/2 5/2/2
+f 4/1/2 7/4/2 6/3/2
+f 4/4/3 5/1/2 8/2/3
+f 8/2/3 5/1/2 4/4/3
+o Ball
+usemtl Glass
+f 5/1/2 6/2/3 8/3/3
+"""
+MTL = """# materials
+newmtl Light
+Ns 0.0
+Kd 0.0 0.0 0.0
+Ke 10.0 12.5 15.0
+Ni 1.0
+
+newmtl Wall
+Ns 500.0
+Kd 0.8 0.7 0.6
+Ks 0.1 0.2 0.3
+Ni 1.00029
+
+newmtl Glass
+Ns 50
+Kd 0.1 0.1 0.1
+Ks 1 1 1
+Ni 1.474
+"""
+
+
+@pytest.fixture()
+def tiny_scene(tmp_path):
+    base = str(tmp_path / "t")
+    open(base + ".obj", "w").write(OBJ)
+    open(base + ".mtl", "w").write(MTL)
+    return base
+
+
+def test_ingest_conventions(tiny_scene):
+    models, shadings, lights, materials = host.load_wavefront(tiny_scene)
+    assert len(models) == 6 and lights == 1 and len(materials) == 3
+    # last usemtl of an object wins (Scene.cpp:633-634): the Lamp object is emissive and comes first
+    assert shadings["material_id"][0] == 0
+    assert np.allclose(materials["emission_ior"][0], [10.0, 12.5, 15.0, 1.0])
+    # Ns / 1000 -> roughness, Ni -> ior
+    assert materials["specular_roughness"][1][3] == np.float32(500.0) / np.float32(1000.0)
+    assert materials["emission_ior"][2][3] == np.float32(1.474)
+    # the rest is ordered by descending |cross(u, v)|; the two equal floor halves keep file order
+    c = np.cross(models["u"][1:], models["v"][1:])
+    area = np.linalg.norm(c, axis=1)
+    assert (np.diff(area) <= 0).all()
+    assert np.array_equal(models["true_normal"][0], np.cross(models["u"][0], models["v"][0]))
+
+
+def test_ingest_matches_numpy_restatement(tiny_scene):
+    models, shadings, lights, materials = host.load_wavefront(tiny_scene)
+    m2, s2, l2, mat2, _ = scene_np.load_wavefront(tiny_scene)
+    assert lights == l2
+    assert models.tobytes() == m2.tobytes()
+    assert materials.tobytes() == mat2.tobytes()
+    for f in ("material_id", "normals", "tex_p", "tex_u", "tex_v"):
+        assert np.array_equal(shadings[f], s2[f]), f
+    assert np.array_equal(shadings["tangents"], s2["tangents"], equal_nan=True)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/res/models"), reason="reference models not present")
+@pytest.mark.parametrize("name", ["cubes", "box", "sphere", "_ObiWan"])
+def test_ingest_of_reference_models_matches_fixtures(name):
+    from conftest import load_scene
+    models, shadings, lights, materials = host.load_wavefront("/root/reference/res/models/" + name)
+    fm, fs, fl, fmat = load_scene(name)
+    assert lights == fl
+    assert models.tobytes() == fm.tobytes() and materials.tobytes() == fmat.tobytes()
+    assert np.array_equal(shadings["material_id"], fs["material_id"])
+    assert np.array_equal(shadings["normals"], fs["normals"])
+    assert np.array_equal(shadings["tangents"], fs["tangents"], equal_nan=True)
+
+
+def test_missing_model_is_an_error(tmp_path):
+    with pytest.raises(ValueError):
+        host.load_wavefront(str(tmp_path / "nothing"))
+
+
+def test_exr_roundtrip(tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 4, size=(13, 17, 3)).astype(np.float32)
+    p = str(tmp_path / "a.exr")
+    host.write_exr(p, img)
+    back = host.read_exr(p)
+    assert back.shape == (13, 17, 4)
+    assert np.array_equal(back[..., :3], img) and (back[..., 3] == 1).all()
+    raw = open(p, "rb").read()
+    assert raw[:4] == bytes([0x76, 0x2F, 0x31, 0x01])            # OpenEXR magic
+    rgba = rng.uniform(0, 1, size=(5, 4, 4)).astype(np.float32)
+    host.write_exr(p, rgba)
+    assert np.array_equal(host.read_exr(p), rgba)
+
+
+def _zip_exr(path, img_half_rgb):
+    """Writes a ZIP-compressed (16-line blocks) HALF RGB scanline EXR with Python, to test the reader."""
+    h, w, _ = img_half_rgb.shape
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
+    ch = b""
+    for n in ("B", "G", "R"):
+        ch += n.encode() + b"\0" + struct.pack("<IBBBBII", 1, 0, 0, 0, 0, 1, 1)
+    ch += b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", ch) + attr("compression", "compression", b"\x03")
+    hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
+    hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    hdr += b"\0"
+    blocks = []
+    for y0 in range(0, h, 16):
+        raw = b""
+        for y in range(y0, min(h, y0 + 16)):
+            for c in (2, 1, 0):
+                raw += img_half_rgb[y, :, c].astype("<f2").tobytes()
+        a = np.frombuffer(raw, np.uint8)
+        inter = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+        pred = inter.copy()
+        pred[1:] = (inter[1:] - inter[:-1] + 128 + 256) % 256
+        z = zlib.compress(pred.astype(np.uint8).tobytes())
+        blocks.append((y0, z if len(z) < len(raw) else raw))      # EXR stores a block raw when zlib does not shrink it
+    off = len(hdr) + 8 * len(blocks)
+    table = b""
+    for _, z in blocks:
+        table += struct.pack("<Q", off)
+        off += 8 + len(z)
+    with open(path, "wb") as fh:
+        fh.write(hdr + table)
+        for y0, z in blocks:
+            fh.write(struct.pack("<ii", y0, len(z)) + z)
+
+
+def test_exr_reader_zip_half(tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.uniform(0, 2, size=(37, 21, 3)).astype(np.float16)
+    p = str(tmp_path / "z.exr")
+    _zip_exr(p, img)
+    back = host.read_exr(p)
+    assert np.array_equal(back[..., :3], img.astype(np.float32))
+
+
+def test_camera_matrix_matches_python_recipe():
+    for t, r in (((0.0, 1.5, -3.0), (-np.pi / 4, 0.0)), ((0.3, 1.2, -2.5), (-0.5, 0.4))):
+        assert np.allclose(host.camera_matrix(t, r), camera_matrix(t, r), atol=1e-7)
