@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--batch-samples", type=int, default=4)
     ap.add_argument("--pipeline", type=int, default=1)
     ap.add_argument("--fuse-shade", type=int, default=1)
+    ap.add_argument("--accel", type=int, default=-1, help="-1 auto, 0 loops over all triangles, 1 hierarchy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -97,6 +98,7 @@ def main():
     ctx.set_option("pipeline", args.pipeline)
     ctx.set_option("batch_samples", args.batch_samples)
     ctx.set_option("fuse_shade", args.fuse_shade)
+    ctx.set_option("accel", args.accel)
     ctx.set_option("profiling", 1)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
@@ -174,6 +176,7 @@ def main():
             "rays_per_pixel_sample": rays / max(1.0, float(st["pixel_samples"]) * world),
             "mean_radiance": mean,
             "nonfinite_pixels": nonfinite_pixels,
+            "bvh": {k: st[k] for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris")},
             "roofline": {
                 "bound": "valu", "kernel": "k_extend<FIRST> (depth-0 brute-force closest hit + shading)",
                 "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",

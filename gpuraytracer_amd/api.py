@@ -26,7 +26,9 @@ class RtStats(ctypes.Structure):
                 ("probe_tests", ctypes.c_uint64), ("trace_ms", ctypes.c_double), ("extend_ms", ctypes.c_double),
                 ("probe_ms", ctypes.c_double), ("shade_ms", ctypes.c_double), ("extend_launches", ctypes.c_uint64),
                 ("probe_launches", ctypes.c_uint64), ("extend0_ms", ctypes.c_double),
-                ("extend0_launches", ctypes.c_uint64)]
+                ("extend0_launches", ctypes.c_uint64), ("bvh_extend_nodes", ctypes.c_uint64),
+                ("bvh_extend_tris", ctypes.c_uint64), ("bvh_probe_nodes", ctypes.c_uint64),
+                ("bvh_probe_tris", ctypes.c_uint64)]
 
 
 class GpuRtError(RuntimeError):

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +17,7 @@
 #include "../../include/gpurt.h"
 #include "rt_kernels.h"
 #include "rt_pipeline.h"
+#include "rt_bvh_build.h"
 
 using namespace rt;
 
@@ -33,6 +35,11 @@ struct rt_context {
     int env_w = 0, env_h = 0;
     int count = 0, lights = 0, n_mat = 0, atlas_size = 4096;
     bool have_scene = false;
+
+    // hierarchies (all triangles; light triangles only), see rt_bvh.h
+    struct DevBvh { float4 *nodes = nullptr, *leaf_geo = nullptr; int *leaf_ids = nullptr; float max_abs = 0.0f; bool ok = false; };
+    DevBvh bvh, light_bvh;
+    int accel = -1;            // -1 auto (hierarchy from ACCEL_AUTO_MIN triangles on), 0 brute force, 1 hierarchy
 
     // target
     uint32_t width = 0, height = 0;
@@ -106,6 +113,48 @@ DScene device_scene(const rt_context *ctx) {
     return sc;
 }
 
+constexpr int ACCEL_AUTO_MIN = 64;
+
+DBvh device_bvh(const rt_context *ctx, const rt_context::DevBvh &b, bool want) {
+    DBvh d;
+    d.nodes = b.nodes;
+    d.leaf_geo = b.leaf_geo;
+    d.leaf_ids = b.leaf_ids;
+    d.max_abs_coord = b.max_abs;
+    d.enabled = (want && b.ok) ? 1 : 0;
+    (void)ctx;
+    return d;
+}
+
+bool use_accel(const rt_context *ctx) {
+    if (!ctx->bvh.ok) return false;
+    if (ctx->accel < 0) return ctx->count >= ACCEL_AUTO_MIN;
+    return ctx->accel != 0;
+}
+
+void free_bvh(rt_context::DevBvh &b) {
+    if (b.nodes) (void)hipFree(b.nodes);
+    if (b.leaf_geo) (void)hipFree(b.leaf_geo);
+    if (b.leaf_ids) (void)hipFree(b.leaf_ids);
+    b = rt_context::DevBvh();
+}
+
+hipError_t upload_bvh(const rt_triangle_model *tris, uint32_t count, rt_context::DevBvh &out) {
+    HostBvh hb;
+    build_bvh(tris, count, hb);
+    hipError_t e = hipMalloc(&out.nodes, hb.nodes.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&out.leaf_geo, std::max<size_t>(1, hb.leaf_geo.size()) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&out.leaf_ids, std::max<size_t>(1, hb.leaf_ids.size()) * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(out.nodes, hb.nodes.data(), hb.nodes.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !hb.leaf_geo.empty())
+        e = hipMemcpy(out.leaf_geo, hb.leaf_geo.data(), hb.leaf_geo.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !hb.leaf_ids.empty())
+        e = hipMemcpy(out.leaf_ids, hb.leaf_ids.data(), hb.leaf_ids.size() * sizeof(int), hipMemcpyHostToDevice);
+    out.max_abs = hb.max_abs_coord;
+    out.ok = e == hipSuccess;
+    return e;
+}
+
 uint32_t pcg_hash_host(uint32_t k) {
     const uint32_t state = k * 747796405u + 2891336453u;
     const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
@@ -143,6 +192,8 @@ void free_scene(rt_context *ctx) {
     ctx->d_geo = ctx->d_shade = ctx->d_mats = nullptr;
     ctx->d_has_tex = nullptr;
     free_atlas(ctx);
+    free_bvh(ctx->bvh);
+    free_bvh(ctx->light_bvh);
     ctx->have_scene = false;
 }
 
@@ -299,6 +350,16 @@ int rt_upload_scene(rt_context *ctx, const rt_triangle_model *models, const rt_t
     ctx->count = (int)count;
     ctx->lights = (int)lights;
     ctx->n_mat = (int)n_materials;
+    // hierarchies need finite geometry; a scene with NaN/Inf coordinates keeps the index-order loops
+    bool finite = true;
+    for (uint32_t i = 0; i < count && finite; i++) {
+        const float *f = (const float *)&models[i];
+        for (int k = 0; k < 12; k++) finite = finite && std::isfinite(f[k]);
+    }
+    if (finite) {
+        HIP_TRY(ctx, upload_bvh(models, count, ctx->bvh));
+        if (lights > 0) HIP_TRY(ctx, upload_bvh(models, lights, ctx->light_bvh));
+    }
     ctx->have_scene = true;
     return RT_OK;
 }
@@ -467,7 +528,8 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
         } else {
             const char *msg = nullptr;
             ctx->pipe.h_light_seeds.assign(seeds.begin(), seeds.begin() + n);
-            hipError_t e = ctx->pipe.run(sc, ctx->frame, ctx->d_sum, ctx->d_samples, ctx->d_light_seeds, (int)n,
+            const bool acc = use_accel(ctx);
+            hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame, ctx->d_sum, ctx->d_samples, ctx->d_light_seeds, (int)n,
                                          ctx->d_stats, ctx->stream, ctx->profiling != 0, ctx->fuse_shade != 0,
                                          &ctx->host_stats, &msg);
             if (e != hipSuccess)
@@ -537,8 +599,12 @@ int rt_closest_hit_batch_device(rt_context *ctx, const float *o_xyz, const float
     if (n > (1ull << 31)) return fail(ctx, RT_ERR_LIMIT, "rt_closest_hit_batch: more than 2^31 rays");
     if (bind_device(ctx)) return RT_ERR_DEVICE;
     const DScene sc = device_scene(ctx);
-    hipLaunchKernelGGL(k_closest_hit_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc, o_xyz,
-                       d_xyz, (unsigned long long)n, id, uvt);
+    if (use_accel(ctx))
+        hipLaunchKernelGGL(k_closest_hit_batch_bvh, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, sc,
+                           device_bvh(ctx, ctx->bvh, true), o_xyz, d_xyz, (unsigned long long)n, id, uvt, ctx->d_stats);
+    else
+        hipLaunchKernelGGL(k_closest_hit_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc, o_xyz,
+                           d_xyz, (unsigned long long)n, id, uvt);
     HIP_TRY(ctx, hipGetLastError());
     return RT_OK;
 }
@@ -592,6 +658,10 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     s.glossy_probes = ds.glossy_probes;
     s.closest_tests = ds.rays * (uint64_t)ctx->count;
     s.probe_tests = (ds.shadow_probes + ds.glossy_probes) * (uint64_t)(ctx->count > 0 ? ctx->count - 1 : 0);
+    s.bvh_extend_nodes = ds.ext_nodes;
+    s.bvh_extend_tris = ds.ext_tris;
+    s.bvh_probe_nodes = ds.probe_nodes;
+    s.bvh_probe_tris = ds.probe_tris;
     *out = s;
     return RT_OK;
 }
@@ -615,6 +685,9 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "batch_samples")) {
         if (value < 1 || value > 64) return fail(ctx, RT_ERR_LIMIT, "batch_samples must be in [1, 64]");
         ctx->batch_samples = (int)value;
+    } else if (!strcmp(name, "accel")) {
+        if (value < -1 || value > 1) return fail(ctx, RT_ERR_INVALID, "accel must be -1 (auto), 0 or 1");
+        ctx->accel = (int)value;
     } else if (!strcmp(name, "fuse_shade")) {
         ctx->fuse_shade = value ? 1 : 0;
     } else if (!strcmp(name, "profiling")) {

@@ -1,0 +1,298 @@
+// rt_bvh.h - hierarchy traversal that reproduces the reference's brute-force results exactly.
+//
+// Why a hierarchy can be exact here.  The shader's closest hit (raytracer.glsl:217-235) is a
+// sequential fold over the triangles in index order: triangle i replaces the running state iff it
+// is front-facing, in front of the origin, inside, and NOT farther than the state, where "farther"
+// is the cross-multiplied float comparison  rd_i * w > z * det_i  (equal depth: the later index
+// wins).  Three facts make the fold reproducible from any visiting order:
+//  1. A triangle that fails facing / in-front / inside never touches the state, so only the
+//     "candidates" that pass those three tests matter, and a hierarchy with conservative boxes
+//     visits every candidate of a ray.
+//  2. Two candidates whose depths differ by far more than float rounding compare the same way in
+//     either order, so every candidate clearly behind the closest one loses to it no matter when it
+//     is met and cannot influence the end state.  (Margin used: relative 2^-12; rounding of the
+//     compared products is below 2^-21.)
+//  3. For a PAIR of candidates a < b the fold's verdict is a function of the pair alone:
+//     b wins unless  rd_b*det_a > rd_a*det_b.  Evaluating that same expression gives the same
+//     verdict whichever of the two is met first.
+// So the traversal keeps one running best, applies rule 3 between it and each new candidate, and
+// counts how many candidates lie within the 2^-12 margin of the smallest depth seen.  With at most two
+// such candidates the running best IS the fold's result.  With three or more (a ray through a
+// mesh vertex, stacked coplanar copies) the lane is re-run through the plain index-order loop.
+//
+// Any-hit queries (sampleLight's occlusion loop :372-378 and the second phase of
+// sampleLightGlossy :406-419) are order-independent ORs of the same per-triangle tests, so they
+// only need the conservative boxes.
+//
+// Conservative boxes: nodes are padded by 4 ulps at build time, and every ray widens them by
+// r = 2^-16 * (largest |coordinate| of the scene and of its origin), far above the rounding of the
+// triangle test (which works on the unrounded p, u, v), far below any geometric feature.
+// Rays with a non-finite origin or direction take the index-order loop (for them "every comparison
+// is false" makes the last triangle win, which no box test reproduces).
+#pragma once
+
+#include "rt_kernels.h"
+
+namespace rt {
+
+struct DBvh {
+    const float4 *nodes;     // 4 x float4 per node
+    const float4 *leaf_geo;  // 3 x float4 per leaf slot
+    const int *leaf_ids;
+    float max_abs_coord;
+    int enabled;
+};
+
+constexpr int BVH_STACK = 48;
+constexpr float BVH_NEAR = 1.0f + 1.0f / 4096.0f;    // 2^-12 depth margin
+
+struct BvhRay {
+    f3 o_lo, o_hi;   // origin shifted by -r / +r: (box.lo - o_hi) and (box.hi - o_lo) widen the box by r
+    f3 inv;
+    bool finite;
+};
+
+RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
+    BvhRay b;
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y)),
+                                    __builtin_fmaxf(__builtin_fabsf(ray.o.z), max_abs_coord));
+    const float r = m * (1.0f / 65536.0f) + 1e-30f;
+    b.o_lo = mk3(ray.o.x - r, ray.o.y - r, ray.o.z - r);
+    b.o_hi = mk3(ray.o.x + r, ray.o.y + r, ray.o.z + r);
+    b.inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
+    b.finite = (s - s) == 0.0f;      // false when any component is NaN or infinite
+    return b;
+}
+
+// Slab test against a box widened by r.  Returns the entry distance (clamped at 0) or a negative
+// value when the box is missed or lies beyond `t_max`.  min/max ignore NaN (0 * inf on a slab
+// boundary), which errs on the side of visiting.
+RT_DEV float box_entry(const BvhRay &br, f3 lo, f3 hi, float t_max) {
+    const float ax = (lo.x - br.o_hi.x) * br.inv.x, bx = (hi.x - br.o_lo.x) * br.inv.x;
+    const float ay = (lo.y - br.o_hi.y) * br.inv.y, by = (hi.y - br.o_lo.y) * br.inv.y;
+    const float az = (lo.z - br.o_hi.z) * br.inv.z, bz = (hi.z - br.o_lo.z) * br.inv.z;
+    float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                               __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+    float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                               __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
+    // widen the exit side for the rounding of the slab arithmetic itself
+    t1 = t1 * 1.0000004f;
+    return (t0 <= t1) ? t0 : -1.0f;
+}
+
+struct BvhCounters { uint32_t nodes, tris; };
+
+// Generic traversal.  `leaf(slot)` is called for every triangle slot of every leaf whose box the ray
+// enters within t_limit(); it returns false to stop the whole traversal (any-hit found).
+// `stack` points at this lane's column of an LDS array [BVH_STACK][64].
+template <typename LeafFn, typename LimitFn>
+RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, int *stack, LeafFn leaf, LimitFn t_limit,
+                         BvhCounters &cnt) {
+    int sp = 0;
+    int node = 0;
+    bool run = active;
+    while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+        if (run) {
+            if (node >= 0) {
+                const float4 q0 = bv.nodes[4 * node + 0], q1 = bv.nodes[4 * node + 1], q2 = bv.nodes[4 * node + 2],
+                             q3 = bv.nodes[4 * node + 3];
+                cnt.nodes++;
+                const float lim = t_limit();
+                const float e0 = box_entry(br, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), lim);
+                const float e1 = box_entry(br, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), lim);
+                const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                const bool h0 = e0 >= 0.0f, h1 = e1 >= 0.0f;
+                if (h0 & h1) {
+                    const bool first0 = e0 <= e1;
+                    stack[64 * sp] = first0 ? c1 : c0;
+                    sp++;
+                    node = first0 ? c0 : c1;
+                } else if (h0 | h1) {
+                    node = h0 ? c0 : c1;
+                } else if (sp > 0) {
+                    sp--;
+                    node = stack[64 * sp];
+                } else {
+                    run = false;
+                }
+            } else {
+                const int code = ~node;
+                const int first = code >> 3, n = code & 7;
+                bool go_on = true;
+                for (int k = 0; k < n; k++) {
+                    cnt.tris++;
+                    if (go_on) go_on = leaf(first + k);
+                }
+                if (go_on && sp > 0) {
+                    sp--;
+                    node = stack[64 * sp];
+                } else {
+                    run = false;
+                }
+            }
+        }
+    }
+}
+
+RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot) {
+    const float4 a = bv.leaf_geo[3 * slot + 0], b = bv.leaf_geo[3 * slot + 1], c = bv.leaf_geo[3 * slot + 2];
+    Tri t;
+    t.n = mk3(a.x, a.y, a.z);
+    t.p = mk3(a.w, b.x, b.y);
+    t.u = mk3(b.z, b.w, c.x);
+    t.v = mk3(c.y, c.z, c.w);
+    return t;
+}
+
+// Closest hit with the reference's fold semantics (see the header comment).  `begin_id`..`end_id`
+// restricts the triangles considered (the glossy probe folds over the light triangles only),
+// `current` is skipped.  Returns the triangle id or -1; isec = (x, y, rd, det) of the winner, or
+// (0, 0, -1, w_init) when nothing was hit.
+RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, int begin_id, int end_id,
+                           int current, float w_init, int *stack, f4 &isec, BvhCounters &cnt) {
+    const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    int best = -1;
+    float t_min = __builtin_inff();
+    int n_near = 0;
+    f4 st;
+    st.x = 0.0f; st.y = 0.0f; st.z = -1.0f; st.w = w_init;
+    auto leaf = [&](int slot) -> bool {
+        const int id = bv.leaf_ids[slot];
+        if (id < begin_id || id >= end_id || id == current) return true;
+        const Tri t = load_leaf_tri(bv, slot);
+        const float det = -dot(ray.d, t.n);
+        const f3 delta = ray.o - t.p;
+        const float rd = dot(t.n, delta);
+        if ((det <= 0.0f) | (rd <= 0.0f)) return true;
+        PlaneTest pt;
+        pt.det = det; pt.rd = rd; pt.delta = delta;
+        float rx, ry;
+        if (!inside_test(ray, t, pt, rx, ry)) return true;
+        // a candidate: rule 3 between it and the running best
+        bool take;
+        if (best < 0) take = true;
+        else if (id > best) take = !(rd * st.w > st.z * det);
+        else take = (st.z * det > rd * st.w);
+        const float tc = rd / det;
+        if (tc * BVH_NEAR < t_min) n_near = 1;
+        else if (tc <= t_min * BVH_NEAR) n_near++;
+        t_min = __builtin_fminf(t_min, tc);
+        if (take) { best = id; st.x = rx; st.y = ry; st.z = rd; st.w = det; }
+        return true;
+    };
+    auto limit = [&]() -> float { return t_min * BVH_NEAR; };
+    bvh_traverse(bv, br, active && br.finite, stack, leaf, limit, cnt);
+
+    // Rare cases, redone by the index-order loop: three or more candidates within the margin of the
+    // closest depth, or a non-finite ray.
+    const bool redo = active && (!br.finite || n_near > 2);
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+        f4 s2;
+        s2.x = 0.0f; s2.y = 0.0f; s2.z = -1.0f; s2.w = w_init;
+        const int b2 = closest_hit_range(sc.geo, begin_id, end_id, ray, redo, current, s2, -1);
+        if (redo) { best = b2; st = s2; }
+    }
+    isec = st;
+    return best;
+}
+
+// sampleLight's occlusion query (raytracer.glsl:372-378): is any triangle != current hit by
+// intersectTriangleShadow within max_t?
+RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
+                               int *stack, BvhCounters &cnt) {
+    const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    const bool ok = br.finite && ((max_t - max_t) == 0.0f);
+    bool blocked = false;
+    auto leaf = [&](int slot) -> bool {
+        const int id = bv.leaf_ids[slot];
+        if (id == current) return true;
+        const Tri t = load_leaf_tri(bv, slot);
+        if (intersect_triangle_shadow(ray, t, max_t)) { blocked = true; return false; }
+        return true;
+    };
+    const float lim = max_t * BVH_NEAR;
+    auto limit = [&]() -> float { return lim; };
+    bvh_traverse(bv, br, active && ok, stack, leaf, limit, cnt);
+    const bool redo = active && !ok;
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+        const bool b2 = shadow_any_hit_bf(sc, ray, max_t, current, redo);
+        if (redo) blocked = b2;
+    }
+    return blocked;
+}
+
+// Second phase of sampleLightGlossy (raytracer.glsl:406-419): does any triangle of [lights, count)
+// other than `current` pass intersectTriangle against the fixed state `isec`?
+RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, const f4 &isec, int current, bool active,
+                               int *stack, BvhCounters &cnt) {
+    const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    const bool bounded = isec.z >= 0.0f;                 // a light was hit: only triangles not farther than it matter
+    const float t_light = isec.z / isec.w;
+    const bool ok = br.finite && (!bounded || (t_light - t_light) == 0.0f);
+    bool blocked = false;
+    const int lights = sc.lights;
+    auto leaf = [&](int slot) -> bool {
+        const int id = bv.leaf_ids[slot];
+        if (id < lights || id == current) return true;
+        const Tri t = load_leaf_tri(bv, slot);
+        PlaneTest pt;
+        float rx, ry;
+        if (plane_test_closest(ray, t, isec, pt) && inside_test(ray, t, pt, rx, ry)) { blocked = true; return false; }
+        return true;
+    };
+    const float lim = bounded ? t_light * BVH_NEAR : __builtin_inff();
+    auto limit = [&]() -> float { return lim; };
+    bvh_traverse(bv, br, active && ok, stack, leaf, limit, cnt);
+    const bool redo = active && !ok;
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+        const bool b2 = closer_any_hit_range(sc.geo, lights < sc.count ? lights : sc.count, sc.count, ray, isec, current, redo);
+        if (redo) blocked = b2;
+    }
+    return blocked;
+}
+
+// sampleLightGlossy's search (raytracer.glsl:403-419) in its two-phase form, see glossy_search_bf.
+// `lbv` is a hierarchy over the light triangles [0, lights) alone.
+RT_DEV int glossy_search_bvh(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &ray, int current, bool active,
+                             int &light_id, f4 &isec, int *stack, BvhCounters &cnt) {
+    const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
+    if (lbv.enabled) {
+        light_id = closest_hit_bvh(sc, lbv, ray, active, 0, lights, current, 0.0f, stack, isec, cnt);
+    } else {
+        isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
+        light_id = closest_hit_range(sc.geo, 0, lights, ray, active, current, isec, -1);
+    }
+    const bool blocked = (lights < count) && closer_any_hit_bvh(sc, bv, ray, isec, current, active, stack, cnt);
+    if (blocked) return 0;
+    return light_id < 0 ? 1 : 2;
+}
+
+// rt_closest_hit_batch through the hierarchy.
+__global__ __launch_bounds__(64) void k_closest_hit_batch_bvh(DScene sc, DBvh bv, const float *__restrict__ o,
+                                                              const float *__restrict__ d, unsigned long long n,
+                                                              int *__restrict__ id, float *__restrict__ uvt,
+                                                              DStats *__restrict__ stats) {
+    __shared__ int stack_mem[BVH_STACK * 64];
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const unsigned long long j = live ? i : 0ull;
+    Ray ray;
+    ray.o = mk3(o[j * 3 + 0], o[j * 3 + 1], o[j * 3 + 2]);
+    ray.d = mk3(d[j * 3 + 0], d[j * 3 + 1], d[j * 3 + 2]);
+    f4 isec;
+    BvhCounters cnt;
+    cnt.nodes = 0; cnt.tris = 0;
+    const int hit = closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, stack_mem + threadIdx.x, isec, cnt);
+    if (live) {
+        const float inv_det = 1.0f / isec.w;
+        id[i] = hit;
+        uvt[i * 3 + 0] = isec.x * inv_det;
+        uvt[i * 3 + 1] = isec.y * inv_det;
+        uvt[i * 3 + 2] = isec.z * inv_det;
+    }
+    const unsigned long long nn = wave_sum_u32(cnt.nodes), nt = wave_sum_u32(cnt.tris);
+    if ((threadIdx.x & 63) == 0 && (nn | nt)) { atomicAdd(&stats->ext_nodes, nn); atomicAdd(&stats->ext_tris, nt); }
+}
+
+}  // namespace rt

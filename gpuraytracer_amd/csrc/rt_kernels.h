@@ -12,6 +12,8 @@ namespace rt {
 // Device-side work counters (see rt_stats in gpurt.h).
 struct DStats {
     unsigned long long pixel_samples, rays, shadow_probes, glossy_probes;
+    // hierarchy traversal work: node visits and triangle tests of the closest-hit and of the probe stages
+    unsigned long long ext_nodes, ext_tris, probe_nodes, probe_tris;
 };
 
 RT_DEV unsigned long long wave_sum_u32(uint32_t v) {

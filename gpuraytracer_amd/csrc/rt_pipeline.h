@@ -31,6 +31,7 @@
 
 #include "../../include/gpurt.h"
 #include "rt_kernels.h"
+#include "rt_bvh.h"
 
 namespace rt {
 
@@ -110,8 +111,8 @@ RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffer
 // pixels itself (raytracer.glsl:586-607) instead of reading a queue.  FUSED: the wave goes on to
 // shade its paths; otherwise it writes the hit record h0 = (u, v, t, triangle id; -1 = miss) and
 // k_shade does the shading, which lets this kernel run with a small register footprint.
-template <bool FIRST, bool FUSED>
-__global__ __launch_bounds__(64) void k_extend(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
+template <bool FIRST, bool FUSED, bool BVH>
+__global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
                                                const uint32_t *__restrict__ samples,
                                                const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
                                                uint32_t n_slots, int max_depth, DStats *__restrict__ stats) {
@@ -120,6 +121,10 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DFrame fr, PipeBuffers
     const uint32_t *__restrict__ q = b.q_ext[q_in];
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
     uint32_t n_paths = 0;
+    __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
+    int *stack = stack_mem + lane;
+    BvhCounters cnt;
+    cnt.nodes = 0; cnt.tris = 0;
 
     for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
         const uint32_t qi = base + lane;
@@ -158,7 +163,8 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DFrame fr, PipeBuffers
         }
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
-        const int hit = closest_hit_bf(sc, ray, isec);
+        const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, stack, isec, cnt)
+                            : closest_hit_bf(sc, ray, isec);
         const float inv_det = 1.0f / isec.w;
         if (FUSED) {
             shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, hit,
@@ -172,6 +178,10 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DFrame fr, PipeBuffers
         if (lane == 0 && p) { atomicAdd(&stats->pixel_samples, p); atomicAdd(&stats->rays, p); }
     } else if (blockIdx.x == 0 && lane == 0) {
         atomicAdd(&stats->rays, (unsigned long long)total);
+    }
+    if (BVH) {
+        const unsigned long long nn = wave_sum_u32(cnt.nodes), nt = wave_sum_u32(cnt.tris);
+        if (lane == 0 && (nn | nt)) { atomicAdd(&stats->ext_nodes, nn); atomicAdd(&stats->ext_tris, nt); }
     }
 }
 
@@ -208,9 +218,14 @@ __global__ __launch_bounds__(64) void k_shade(DScene sc, DFrame fr, PipeBuffers 
 }
 
 // Shadow-probe stage: occlusion loop of sampleLight (raytracer.glsl:372-378), then :557-579.
-__global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, PipeBuffers b, int depth, int q_in, int max_depth,
+template <bool BVH>
+__global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in, int max_depth,
                                                      DStats *__restrict__ stats) {
     const uint32_t lane = threadIdx.x;
+    __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
+    int *stack = stack_mem + lane;
+    BvhCounters bc;
+    bc.nodes = 0; bc.tris = 0;
     uint32_t *cnt = b.counters + 4 * depth;
     uint32_t *cnt_next = b.counters + 4 * (depth + 1);
     const uint32_t total = cnt[1];
@@ -224,7 +239,8 @@ __global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, PipeBuffers b, i
         Ray probe;
         probe.o = mk3(a.x, a.y, a.z);
         probe.d = mk3(pr.x, pr.y, pr.z);
-        const bool blocked = shadow_any_hit_bf(sc, probe, pr.w, (int)sc3.y, live);
+        const bool blocked = BVH ? shadow_any_hit_bvh(sc, bv, probe, pr.w, (int)sc3.y, live, stack, bc)
+                                 : shadow_any_hit_bf(sc, probe, pr.w, (int)sc3.y, live);
         bool to_next = false;
         if (live) {
             PathState ps;
@@ -241,12 +257,21 @@ __global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, PipeBuffers b, i
         queue_push(q_next, cnt_next + 0, to_next, id);
     }
     if (blockIdx.x == 0 && lane == 0) atomicAdd(&stats->shadow_probes, (unsigned long long)total);
+    if (BVH) {
+        const unsigned long long nn = wave_sum_u32(bc.nodes), nt = wave_sum_u32(bc.tris);
+        if (lane == 0 && (nn | nt)) { atomicAdd(&stats->probe_nodes, nn); atomicAdd(&stats->probe_tris, nt); }
+    }
 }
 
 // Glossy-probe stage: search loop of sampleLightGlossy (raytracer.glsl:403-437), then :557-579.
-__global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
-                                                     int max_depth, DStats *__restrict__ stats) {
+template <bool BVH>
+__global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth,
+                                                     int q_in, int max_depth, DStats *__restrict__ stats) {
     const uint32_t lane = threadIdx.x;
+    __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
+    int *stack = stack_mem + lane;
+    BvhCounters bc;
+    bc.nodes = 0; bc.tris = 0;
     uint32_t *cnt = b.counters + 4 * depth;
     uint32_t *cnt_next = b.counters + 4 * (depth + 1);
     const uint32_t total = cnt[2];
@@ -262,7 +287,8 @@ __global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DFrame fr, PipeB
         probe.d = mk3(pr.x, pr.y, pr.z);
         int light_id;
         f4 lsec;
-        const int outcome = glossy_search_bf(sc, probe, (int)sc3.y, live, light_id, lsec);
+        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, probe, (int)sc3.y, live, light_id, lsec, stack, bc)
+                                : glossy_search_bf(sc, probe, (int)sc3.y, live, light_id, lsec);
         bool to_next = false;
         if (live) {
             PathState ps;
@@ -283,6 +309,10 @@ __global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DFrame fr, PipeB
         queue_push(q_next, cnt_next + 0, to_next, id);
     }
     if (blockIdx.x == 0 && lane == 0) atomicAdd(&stats->glossy_probes, (unsigned long long)total);
+    if (BVH) {
+        const unsigned long long nn = wave_sum_u32(bc.nodes), nt = wave_sum_u32(bc.tris);
+        if (lane == 0 && (nn | nt)) { atomicAdd(&stats->probe_nodes, nn); atomicAdd(&stats->probe_tris, nt); }
+    }
 }
 
 // Resolve stage: sum[pixel] += energy of the batch's samples, ascending slot order.
@@ -377,7 +407,7 @@ struct Pipeline {
     }
 
     // Renders the `n` samples listed in d_samples (light seeds in h_light_seeds order) and adds them to `sum`.
-    hipError_t run(const DScene &sc, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
+    hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
                    const uint32_t *d_light_seeds, int n, DStats *d_stats, hipStream_t stream, bool profiling,
                    bool fused, rt_stats *host_stats, const char **what);
 
@@ -391,10 +421,16 @@ struct Pipeline {
                 float ms = 0.0f;
                 e = hipEventElapsedTime(&ms, events[i], events[i + 1]);
                 if (e != hipSuccess) break;
-                if (kinds[i] == 0 || kinds[i] == 3) { host_stats->extend_ms += ms; host_stats->extend_launches++; }
-                if (kinds[i] == 3) { host_stats->extend0_ms += ms; host_stats->extend0_launches++; }
-                else if (kinds[i] == 2) { host_stats->shade_ms += ms; }
-                else { host_stats->probe_ms += ms; host_stats->probe_launches += 2; }
+                if (kinds[i] == 0 || kinds[i] == 3) {
+                    host_stats->extend_ms += ms;
+                    host_stats->extend_launches++;
+                    if (kinds[i] == 3) { host_stats->extend0_ms += ms; host_stats->extend0_launches++; }
+                } else if (kinds[i] == 2) {
+                    host_stats->shade_ms += ms;
+                } else {
+                    host_stats->probe_ms += ms;
+                    host_stats->probe_launches += 2;
+                }
             }
         }
         ev_used = 0;
@@ -406,10 +442,11 @@ struct Pipeline {
     std::vector<uint32_t> h_light_seeds;
 };
 
-inline hipError_t Pipeline::run(const DScene &sc, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
+inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
                                 const uint32_t *d_light_seeds, int n, DStats *d_stats, hipStream_t stream,
                                 bool profiling, bool fused, rt_stats *host_stats, const char **what) {
     (void)d_light_seeds;
+    const bool use_bvh = bvh.enabled != 0;
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
     const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
     const uint32_t pps = tiles * 64u;
@@ -452,21 +489,16 @@ inline hipError_t Pipeline::run(const DScene &sc, const DFrame &fr, float4 *sum,
     int q_in = 0;
     for (int depth = 0; depth < max_depth; depth++) {
         PIPE_TRY(stamp(depth == 0 ? 3 : 0));
+#define LAUNCH_EXTEND(F, FU, BV, G)                                                                              \
+    hipLaunchKernelGGL((k_extend<F, FU, BV>), G, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples, d_coins, \
+                       pps, (uint32_t)n, max_depth, d_stats)
         if (fused) {
-            if (depth == 0)
-                hipLaunchKernelGGL((k_extend<true, true>), grid0, block, 0, stream, sc, fr, buf, depth, q_in, d_samples,
-                                   d_coins, pps, (uint32_t)n, max_depth, d_stats);
-            else
-                hipLaunchKernelGGL((k_extend<false, true>), grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples,
-                                   d_coins, pps, (uint32_t)n, max_depth, d_stats);
+            if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, true, true, grid0); else LAUNCH_EXTEND(true, true, false, grid0); }
+            else { if (use_bvh) LAUNCH_EXTEND(false, true, true, grid); else LAUNCH_EXTEND(false, true, false, grid); }
             PIPE_TRY(hipGetLastError());
         } else {
-            if (depth == 0)
-                hipLaunchKernelGGL((k_extend<true, false>), grid0, block, 0, stream, sc, fr, buf, depth, q_in, d_samples,
-                                   d_coins, pps, (uint32_t)n, max_depth, d_stats);
-            else
-                hipLaunchKernelGGL((k_extend<false, false>), grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples,
-                                   d_coins, pps, (uint32_t)n, max_depth, d_stats);
+            if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, false, true, grid0); else LAUNCH_EXTEND(true, false, false, grid0); }
+            else { if (use_bvh) LAUNCH_EXTEND(false, false, true, grid); else LAUNCH_EXTEND(false, false, false, grid); }
             PIPE_TRY(hipGetLastError());
             PIPE_TRY(stamp(2));
             if (depth == 0)
@@ -477,10 +509,19 @@ inline hipError_t Pipeline::run(const DScene &sc, const DFrame &fr, float4 *sum,
                                    (uint32_t)n, max_depth);
             PIPE_TRY(hipGetLastError());
         }
+#undef LAUNCH_EXTEND
         PIPE_TRY(stamp(1));
-        hipLaunchKernelGGL(k_probe_shadow, grid, block, 0, stream, sc, buf, depth, q_in, max_depth, d_stats);
-        PIPE_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_probe_glossy, grid, block, 0, stream, sc, fr, buf, depth, q_in, max_depth, d_stats);
+        if (use_bvh) {
+            hipLaunchKernelGGL(k_probe_shadow<true>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth, d_stats);
+            PIPE_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_probe_glossy<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
+                               max_depth, d_stats);
+        } else {
+            hipLaunchKernelGGL(k_probe_shadow<false>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth, d_stats);
+            PIPE_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_probe_glossy<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
+                               max_depth, d_stats);
+        }
         PIPE_TRY(hipGetLastError());
         PIPE_TRY(stamp(-1));
         q_in ^= 1;

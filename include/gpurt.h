@@ -65,8 +65,8 @@ typedef struct rt_stats {
     uint64_t rays;              /* findIntersection executions (paths x bounces) */
     uint64_t shadow_probes;     /* sampleLight calls that reached the occlusion loop */
     uint64_t glossy_probes;     /* sampleLightGlossy calls */
-    uint64_t closest_tests;     /* ray-triangle closest-hit tests charged (brute force: rays * COUNT) */
-    uint64_t probe_tests;       /* ray-triangle probe tests charged */
+    uint64_t closest_tests;     /* rays * COUNT: the tests the reference's loop would run */
+    uint64_t probe_tests;       /* probes * (COUNT - 1), likewise */
     double   trace_ms;          /* device time of all rt_trace kernels (HIP events on the context stream) */
     double   extend_ms;         /* part of trace_ms spent in closest-hit kernels */
     double   probe_ms;          /* part of trace_ms spent in light-probe kernels */
@@ -75,6 +75,8 @@ typedef struct rt_stats {
     uint64_t probe_launches;
     double   extend0_ms;        /* part of extend_ms spent in the depth-0 (camera ray) closest-hit launches */
     uint64_t extend0_launches;
+    /* hierarchy traversal (option "accel"): node visits and triangle tests actually executed */
+    uint64_t bvh_extend_nodes, bvh_extend_tris, bvh_probe_nodes, bvh_probe_tris;
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -163,6 +165,8 @@ int rt_reset_stats(rt_context *ctx);
  *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
  *                   1 = staged kernels over compacted ray queues (default)
  *   "batch_samples" samples rendered per pass of the staged pipeline (default 4)
+ *   "accel"         -1 = bounding-volume hierarchy for scenes of 64 triangles or more (default),
+ *                   0 = the reference's loops over all triangles, 1 = hierarchy always; results are identical
  *   "fuse_shade"    1 = the closest-hit kernel also shades its paths (default), 0 = separate shade kernel
  *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
 int rt_set_option(rt_context *ctx, const char *name, int64_t value);

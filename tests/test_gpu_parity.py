@@ -22,8 +22,10 @@ def _upload(ctx, scene, env):
 
 
 def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM):
-    # pipeline 0 = single kernel, 1 = staged with fused shading, 2 = staged with a separate shade kernel
+    # pipeline 0 = single kernel, 1 = staged with fused shading, 2 = staged with a separate shade kernel,
+    # 3 = staged, loops over all triangles instead of the hierarchy (1 and 2 use the hierarchy)
     ctx.set_option("fuse_shade", 0 if pipeline == 2 else 1)
+    ctx.set_option("accel", 0 if pipeline == 3 else 1)
     pipeline = min(pipeline, 1)
     ctx.set_option("pipeline", pipeline)
     ctx.set_option("batch_samples", batch)
@@ -35,11 +37,13 @@ def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK,
     return img, ctx.stats()
 
 
+@pytest.mark.parametrize("accel", [0, 1])
 @pytest.mark.parametrize("name", ["cubes", "_ObiWan"])
-def test_closest_hit_ids_bit_exact(gpu_ctx, oracle_mod, name):
+def test_closest_hit_ids_bit_exact(gpu_ctx, oracle_mod, name, accel):
     g = np.load(os.path.join(GOLDEN, "rays_%s.npz" % name))
     scene = load_scene(name)
     _upload(gpu_ctx, scene, constant_env())
+    gpu_ctx.set_option("accel", accel)
     ids, uvt = gpu_ctx.closest_hit_batch(g["o"], g["d"])
     assert np.array_equal(ids, g["ids"])
     assert np.array_equal(uvt.view(np.uint32), g["uvt"].view(np.uint32))
@@ -53,8 +57,10 @@ def test_closest_hit_ids_bit_exact(gpu_ctx, oracle_mod, name):
     assert np.array_equal(ids, want_ids) and np.array_equal(uvt.view(np.uint32), want_uvt.view(np.uint32))
 
 
-def test_closest_hit_edge_cases(gpu_ctx, oracle_mod, cubes):
+@pytest.mark.parametrize("accel", [0, 1])
+def test_closest_hit_edge_cases(gpu_ctx, oracle_mod, cubes, accel):
     _upload(gpu_ctx, cubes, constant_env())
+    gpu_ctx.set_option("accel", accel)
     sc = oracle_mod.OracleScene(*cubes)
     # empty batch, one ray, a batch that is not a multiple of the block size, NaN / zero directions
     ids, uvt = gpu_ctx.closest_hit_batch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
@@ -68,7 +74,37 @@ def test_closest_hit_edge_cases(gpu_ctx, oracle_mod, cubes):
     assert ids[1] == len(cubes[0]) - 1          # an all-NaN ray passes every rejection: last triangle wins
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2])
+@pytest.mark.parametrize("name", ["cubes", "_ObiWan", "sphere"])
+def test_hierarchy_equals_index_order_loop(gpu_ctx, name):
+    # 400k rays: camera-like, random, and aimed exactly at vertices / edge midpoints / coincident
+    # points, where three or more triangles tie in depth and the later index has to win
+    models, shadings, lights, materials = load_scene(name)
+    _upload(gpu_ctx, (models, shadings, lights, materials), constant_env())
+    rng = np.random.default_rng(99)
+    n = 400000
+    p0 = models["position"]
+    verts = np.concatenate([p0, p0 + models["u"], p0 + models["v"]]).astype(np.float64)
+    lo, hi = verts.min(0), verts.max(0)
+    o = rng.uniform(lo - 1, hi + 1, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    k = n // 2
+    tri = rng.integers(0, len(models), size=k)
+    a, b, c = p0[tri].astype(np.float64), (p0 + models["u"])[tri].astype(np.float64), (p0 + models["v"])[tri].astype(np.float64)
+    w = rng.integers(0, 5, size=k)[:, None]
+    target = np.where(w == 0, a, np.where(w == 1, b, np.where(w == 2, c, np.where(w == 3, 0.5 * (a + b), (a + b + c) / 3))))
+    d[:k] = target - o[:k]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o32, d32 = o.astype(np.float32), d.astype(np.float32)
+    gpu_ctx.set_option("accel", 0)
+    ids0, uvt0 = gpu_ctx.closest_hit_batch(o32, d32)
+    gpu_ctx.set_option("accel", 1)
+    ids1, uvt1 = gpu_ctx.closest_hit_batch(o32, d32)
+    assert np.array_equal(ids0, ids1), int((ids0 != ids1).sum())
+    assert np.array_equal(uvt0.view(np.uint32), uvt1.view(np.uint32))
+    assert (ids0 >= 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
 def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
     _upload(gpu_ctx, cubes, constant_env())
     for spp in (1, 4, 16):
@@ -78,7 +114,7 @@ def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
         assert [st["pixel_samples"], st["rays"], st["shadow_probes"], st["glossy_probes"]] == g["stats"].tolist()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
 def test_image_vs_checker_gradient_env_ragged(gpu_ctx, oracle_mod, cubes, pipeline):
     # 52 x 37 is not a multiple of the 8 x 8 tile; the gradient environment exercises the bilinear lookup
     _upload(gpu_ctx, cubes, gradient_env())
@@ -104,7 +140,7 @@ def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
     sc.upload_env(gradient_env())
     cam = camera_matrix((0.0, 1.0, -2.0), (-0.3, 0.0))
     want, wst = sc.render(cam, DEFAULT_CLOCK, 16, 1.0, 32, 24, 0, 3)
-    for pipeline in (0, 1, 2):
+    for pipeline in (0, 1, 2, 3):
         img, st = _render(gpu_ctx, 32, 24, 0, 3, recursion=16, pipeline=pipeline, batch=2, cam=cam)
         assert np.array_equal(img, want, equal_nan=True), pipeline
         assert st["rays"] == wst["rays"] and st["glossy_probes"] == wst["glossy_probes"]
@@ -169,7 +205,7 @@ def test_textured_materials_bit_exact(gpu_ctx, oracle_mod, cubes):
         target.upload_atlas_layer(2, 2, arm)
         target.set_has_texture(np.array([0, 0, 1, 0], np.int32))
     want, wst = sc.render(CAM, 4242, 6, 1.0, 48, 32, 0, 4)
-    for pipeline in (0, 1, 2):
+    for pipeline in (0, 1, 2, 3):
         img, st = _render(gpu_ctx, 48, 32, 0, 4, clock=4242, pipeline=pipeline)
         assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
         assert st["rays"] == wst["rays"]

@@ -20,6 +20,7 @@ def main():
     ctx = g.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.upload_scene(*scene)
+    ctx.set_option("accel", int(os.environ.get("ACCEL", "-1")))
     cam = torch.tensor(g.camera_matrix().reshape(4, 4).T.copy(), device="cuda")
     # coherent: 8x8-tiled camera rays; incoherent: random directions from points near the camera
     idx = torch.arange(n, device="cuda")
