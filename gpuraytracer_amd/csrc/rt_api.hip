@@ -453,6 +453,7 @@ int rt_resize(rt_context *ctx, uint32_t width, uint32_t height) {
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_sum, 0, sizeof(float4) * (size_t)width * height, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(DStats), ctx->stream));
+    HIP_TRY(ctx, ctx->pipe.reset_wstats(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->width = width;
     ctx->height = height;
@@ -529,9 +530,9 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
             const char *msg = nullptr;
             ctx->pipe.h_light_seeds.assign(seeds.begin(), seeds.begin() + n);
             const bool acc = use_accel(ctx);
-            hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame, ctx->d_sum, ctx->d_samples, ctx->d_light_seeds, (int)n,
-                                         ctx->d_stats, ctx->stream, ctx->profiling != 0, ctx->fuse_shade != 0,
-                                         &ctx->host_stats, &msg);
+            hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame,
+                                         ctx->d_sum, ctx->d_samples, (int)n, ctx->stream, ctx->profiling != 0,
+                                         ctx->fuse_shade != 0, &ctx->host_stats, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
                             msg ? msg : "pipeline", hipGetErrorString(e));
@@ -651,6 +652,16 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     }
     DStats ds;
     HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
+    unsigned long long ws[8];
+    HIP_TRY(ctx, ctx->pipe.read_wstats(ws));
+    ds.pixel_samples += ws[WSTAT_PATHS];
+    ds.rays += ws[WSTAT_RAYS];
+    ds.shadow_probes += ws[WSTAT_SHADOW];
+    ds.glossy_probes += ws[WSTAT_GLOSSY];
+    ds.ext_nodes += ws[WSTAT_EXT_NODES];
+    ds.ext_tris += ws[WSTAT_EXT_TRIS];
+    ds.probe_nodes += ws[WSTAT_PROBE_NODES];
+    ds.probe_tris += ws[WSTAT_PROBE_TRIS];
     rt_stats s = ctx->host_stats;
     s.pixel_samples = ds.pixel_samples;
     s.rays = ds.rays;
@@ -671,6 +682,8 @@ int rt_reset_stats(rt_context *ctx) {
     if (bind_device(ctx)) return RT_ERR_DEVICE;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemset(ctx->d_stats, 0, sizeof(DStats)));
+    HIP_TRY(ctx, ctx->pipe.reset_wstats(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
     rt_stats scratch;
     HIP_TRY(ctx, ctx->pipe.collect_times(&scratch));

@@ -43,7 +43,7 @@ struct DBvh {
     int enabled;
 };
 
-constexpr int BVH_STACK = 48;
+constexpr int BVH_STACK = 32;
 constexpr float BVH_NEAR = 1.0f + 1.0f / 4096.0f;    // 2^-12 depth margin
 
 struct BvhRay {

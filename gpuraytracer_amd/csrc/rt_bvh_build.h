@@ -210,7 +210,7 @@ inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool f
     }
 }
 
-constexpr int BVH_STACK_DEPTH = 48;
+constexpr int BVH_STACK_DEPTH = 32;
 
 inline void build_bvh(const rt_triangle_model *tris, uint32_t count, HostBvh &out) {
     build_bvh_impl(tris, count, false, out);

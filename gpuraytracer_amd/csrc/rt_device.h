@@ -438,10 +438,12 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
     const float ior = material.ior;
     const float variance = roughness * roughness;
 
-    const f3 specular_ray = normalize(reflect(ps.d, normal));                              // :489-492
-    const f3 scattered_specular_ray = normalize(random_sphere(ps.seed) * variance + specular_ray);
-    const f3 scattered_diffuse = normalize(random_sphere(ps.seed) + normal);
-    const f3 scattered_glossy_ray = normalize(random_sphere(ps.seed) * variance + normal);
+    // The shader builds all three scattered directions (:489-492) and then uses one (:509-547).  Their
+    // six random numbers are drawn here in the shader's order; sin/cos/sqrt/normalize run only for
+    // the direction that is used.
+    const float th1 = TWO_PI_F * unit_float(ps.seed), x1 = unit_float(ps.seed) * 2.0f - 1.0f;   // specular scatter
+    const float th2 = TWO_PI_F * unit_float(ps.seed), x2 = unit_float(ps.seed) * 2.0f - 1.0f;   // diffuse
+    const float th3 = TWO_PI_F * unit_float(ps.seed), x3 = unit_float(ps.seed) * 2.0f - 1.0f;   // glossy
 
     const float cos_theta = gmax(-dot(normal, ps.d), 0.0f);
     const float transmission = (ior == 0.0f) ? 0.0f : get_transmission(cos_theta, 1.00029f, ior);
@@ -454,16 +456,30 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
     const f3 old_o = ps.o;
     ps.o = ps.o + ps.d * ht;                                                               // :507
 
-    if (rand_reflectance < fresnel) {                                                      // :509-514
+    const bool is_mirror = rand_reflectance < fresnel;                                     // :509
+    const bool is_metal = !is_mirror && (rand_metallic < metallic);                        // :516
+    const bool is_diffuse = !is_mirror && !is_metal && (rand_scatter < roughness);         // :524
+    f3 specular_ray = mk3(0.0f, 0.0f, 0.0f);
+    if (is_mirror || is_metal) specular_ray = normalize(reflect(ps.d, normal));            // :489
+    f3 new_d = specular_ray;
+    if (!is_mirror) {
+        const float th = is_metal ? th1 : (is_diffuse ? th2 : th3);
+        const float x = is_metal ? x1 : (is_diffuse ? x2 : x3);
+        const float scale = is_diffuse ? 1.0f : variance;          // sphere * 1.0f + normal == sphere + normal
+        const f3 base = is_metal ? specular_ray : normal;
+        const float sinx = __builtin_sqrtf(1.0f - x * x);
+        float sn, cs;
+        dm::sincos(th, sn, cs);
+        new_d = normalize(mk3(sinx * cs, sinx * sn, x) * scale + base);                    // :490-492
+    }
+    if (is_mirror) {                                                                       // :509-514
         const float k = 1.0f - roughness;
         ps.path = ps.path * ((rand_metallic < metallic) ? mk3(k, k, k) : specular);
-        ps.d = specular_ray;
-    } else if (rand_metallic < metallic) {                                                 // :516-522
+    } else if (is_metal) {                                                                 // :516-522
         ps.path = ps.path * albedo;
-        ps.d = scattered_specular_ray;
-    } else if (rand_scatter < roughness) {                                                 // :524-538
+    } else if (is_diffuse) {                                                               // :524-538
         const float theta_i = dm::acos(cos_theta);
-        const float theta_o = dm::acos(dot(scattered_diffuse, normal));
+        const float theta_o = dm::acos(dot(new_d, normal));
         const float var2 = roughness * roughness;
         const float A = 1.0f - 0.5f * var2 / (var2 + 0.33f);
         const float B = 0.45f * var2 / (var2 + 0.09f);
@@ -471,11 +487,10 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
         const float beta = gmin(theta_i, theta_o);
         const float w = (A + B * gmax(0.0f, theta_i - theta_o) * dm::sin(alpha) * dm::tan(beta)) * INV_PI_F * occlusion;
         ps.path = ps.path * (albedo * w);
-        ps.d = scattered_diffuse;
     } else {                                                                               // :539-545
         ps.path = ps.path * (specular * (1.0f - roughness));
-        ps.d = scattered_glossy_ray;
     }
+    ps.d = new_d;
 
     bn.current = hit;
     bn.kind = PROBE_NONE;

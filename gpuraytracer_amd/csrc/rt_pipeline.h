@@ -35,15 +35,26 @@
 
 namespace rt {
 
+constexpr int PIPE_WAVES = 256 * 16;    // persistent grid: 16 single-wave workgroups per CU, all resident
+
+// Queues without atomics.  Every pipeline kernel runs exactly PIPE_WAVES single-wave workgroups, and
+// wave v owns region v of every queue: it is the only one that appends to it (keeping the fill count
+// in a scalar register and storing it once at the end) and the only one that later consumes it.  A
+// wave can never emit more entries than it consumed, so a region of ceil(chunks / PIPE_WAVES) * 64
+// entries always suffices.  With one atomic per wave and queue on three shared counters the shade
+// stage spent 87 % of its time waiting (2.2 ms for 8.3 M paths); the regions took that away.
 struct PipeBuffers {
     float4 *s0, *s1, *s2, *p0, *p1, *h0;
     uint2 *s3;
-    uint32_t *q_ext[2];
-    uint32_t *q_shadow, *q_glossy;
-    uint32_t *counters;   // [depth][4]: 0 extend count, 1 shadow count, 2 glossy count, 3 unused
+    uint32_t *q_ext[2], *q_shadow, *q_glossy;   // PIPE_WAVES regions of region_cap path ids each
+    uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
+    uint32_t region_cap;
+    unsigned long long *wstats;                 // [PIPE_WAVES][8] per-wave work counters (see WSTAT_*)
+    uint32_t *total;                            // scratch word for the early-stop read-back
 };
 
-constexpr int PIPE_WAVES = 256 * 16;    // persistent grid: 16 single-wave workgroups per CU
+enum { WSTAT_PATHS = 0, WSTAT_RAYS, WSTAT_SHADOW, WSTAT_GLOSSY, WSTAT_EXT_NODES, WSTAT_EXT_TRIS, WSTAT_PROBE_NODES,
+       WSTAT_PROBE_TRIS };
 
 RT_DEV void load_path(const PipeBuffers &b, uint32_t id, PathState &ps) {
     const float4 a = b.s0[id], c = b.s1[id], e = b.s2[id];
@@ -58,28 +69,26 @@ RT_DEV void store_path(const PipeBuffers &b, uint32_t id, const PathState &ps) {
     b.s2[id] = make_float4(ps.path.z, ps.energy.x, ps.energy.y, ps.energy.z);
 }
 
-// Appends `id` of every lane with `pred` to a queue: one atomic per wave.
-RT_DEV void queue_push(uint32_t *__restrict__ queue, uint32_t *__restrict__ counter, bool pred, uint32_t id) {
+// Appends `id` of every lane with `pred` to this wave's queue region; `fill` is wave-uniform.
+RT_DEV void region_push(uint32_t *__restrict__ region, uint32_t &fill, bool pred, uint32_t id) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(pred);
-    if (mask == 0ull) return;
-    const uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t base = 0;
-    if (lane_rank == 0 && pred) base = atomicAdd(counter, total);
-    // the lane that did the atomic is the lowest set bit of mask
-    const int leader = __ffsll((long long)mask) - 1;
-    base = __shfl(base, leader, 64);
-    if (pred) queue[base + lane_rank] = id;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (pred) region[fill + rank] = id;
+    fill += (uint32_t)__popcll(mask);
 }
+
+RT_DEV void wstat_add(const PipeBuffers &b, int which, unsigned long long v) {
+    if (threadIdx.x == 0 && v) b.wstats[(size_t)blockIdx.x * 8 + which] += v;
+}
+
+struct RouteFill { uint32_t shadow, glossy, next; };
 
 // Shading of one path after its closest hit is known (raytracer.glsl:452-556): adds the sky on a
 // miss, otherwise runs shade_pre and routes the path to the shadow queue, the glossy queue or (no
 // probe needed) through shade_post to the next extend queue.  Called by whole waves; `live` masks lanes.
 RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffers &b, int depth, int q_in,
                             const uint32_t *__restrict__ coins, uint32_t paths_per_sample, int max_depth, bool live,
-                            uint32_t id, PathState &ps, int hit, float hu, float hv, float ht) {
-    uint32_t *cnt = b.counters + 4 * depth;
-    uint32_t *cnt_next = b.counters + 4 * (depth + 1);
+                            uint32_t id, PathState &ps, int hit, float hu, float hv, float ht, RouteFill &fill) {
     bool to_shadow = false, to_glossy = false, to_next = false;
     if (live) {
         if (hit < 0) {
@@ -102,31 +111,43 @@ RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffer
         store_path(b, id, ps);
     }
     to_next = to_next && (depth + 1 < max_depth);
-    queue_push(b.q_shadow, cnt + 1, to_shadow, id);
-    queue_push(b.q_glossy, cnt + 2, to_glossy, id);
-    queue_push(b.q_ext[q_in ^ 1], cnt_next + 0, to_next, id);
+    const size_t region = (size_t)blockIdx.x * b.region_cap;
+    region_push(b.q_shadow + region, fill.shadow, to_shadow, id);
+    region_push(b.q_glossy + region, fill.glossy, to_glossy, id);
+    region_push(b.q_ext[q_in ^ 1] + region, fill.next, to_next, id);
 }
 
-// Extend stage: the closest-hit loop.  FIRST: depth 0, the wave generates the camera rays of its 64
+RT_DEV void store_route_fill(const PipeBuffers &b, int q_in, const RouteFill &fill) {
+    if (threadIdx.x == 0) {
+        b.n_shadow[blockIdx.x] = fill.shadow;
+        b.n_glossy[blockIdx.x] = fill.glossy;
+        b.n_ext[q_in ^ 1][blockIdx.x] = fill.next;
+    }
+}
+
+// Extend stage: the closest-hit search.  FIRST: depth 0, the wave generates the camera rays of its
 // pixels itself (raytracer.glsl:586-607) instead of reading a queue.  FUSED: the wave goes on to
 // shade its paths; otherwise it writes the hit record h0 = (u, v, t, triangle id; -1 = miss) and
-// k_shade does the shading, which lets this kernel run with a small register footprint.
+// k_shade does the shading.  BVH: hierarchy traversal instead of the loop over all triangles.
 template <bool FIRST, bool FUSED, bool BVH>
 __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
                                                const uint32_t *__restrict__ samples,
                                                const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
-                                               uint32_t n_slots, int max_depth, DStats *__restrict__ stats) {
+                                               uint32_t n_slots, int max_depth) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.counters[4 * depth];
-    const uint32_t *__restrict__ q = b.q_ext[q_in];
+    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][blockIdx.x];
+    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)blockIdx.x * b.region_cap;
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
-    uint32_t n_paths = 0;
     __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
     int *stack = stack_mem + lane;
-    BvhCounters cnt;
-    cnt.nodes = 0; cnt.tris = 0;
+    BvhCounters bc;
+    bc.nodes = 0; bc.tris = 0;
+    uint32_t n_paths = 0, n_rays = 0;
+    RouteFill fill;
+    fill.shadow = fill.glossy = fill.next = 0;
 
-    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+    // FIRST: chunks blockIdx, blockIdx + PIPE_WAVES, ... of the identity queue; else this wave's region
+    for (uint32_t base = FIRST ? blockIdx.x * 64u : 0u; base < total; base += FIRST ? gridDim.x * 64u : 64u) {
         const uint32_t qi = base + lane;
         bool live = qi < total;
         uint32_t id = 0;
@@ -144,12 +165,9 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, Pi
             ps.o = cam.o; ps.d = cam.d;
             ps.path = mk3(1.0f, 1.0f, 1.0f);
             ps.energy = mk3(0.0f, 0.0f, 0.0f);
-            if (live && (!FUSED || !in_image)) {     // padding lanes of ragged tiles too: their energy stays 0
-                store_path(b, id, ps);
-                b.s3[id] = make_uint2(ps.seed, 0u);
-            }
+            if (live && !in_image) store_path(b, id, ps);   // padding lanes of ragged tiles: energy 0 for the resolve stage
             live = live && in_image;
-            n_paths += live ? 1u : 0u;
+            n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         } else {
             id = live ? q[qi] : 0u;
             if (FUSED) {
@@ -161,79 +179,86 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, Pi
                 ps.d = mk3(a.w, c.x, c.y);
             }
         }
+        n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
-        const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, stack, isec, cnt)
+        const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, stack, isec, bc)
                             : closest_hit_bf(sc, ray, isec);
         const float inv_det = 1.0f / isec.w;
         if (FUSED) {
             shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, hit,
-                            isec.x * inv_det, isec.y * inv_det, isec.z * inv_det);
+                            isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, fill);
         } else if (live) {
             b.h0[id] = make_float4(isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, __int_as_float(hit));
         }
     }
-    if (FIRST) {
-        const unsigned long long p = wave_sum_u32(n_paths);
-        if (lane == 0 && p) { atomicAdd(&stats->pixel_samples, p); atomicAdd(&stats->rays, p); }
-    } else if (blockIdx.x == 0 && lane == 0) {
-        atomicAdd(&stats->rays, (unsigned long long)total);
-    }
+    if (FUSED) store_route_fill(b, q_in, fill);
+    if (FIRST) wstat_add(b, WSTAT_PATHS, n_paths);
+    wstat_add(b, WSTAT_RAYS, n_rays);
     if (BVH) {
-        const unsigned long long nn = wave_sum_u32(cnt.nodes), nt = wave_sum_u32(cnt.tris);
-        if (lane == 0 && (nn | nt)) { atomicAdd(&stats->ext_nodes, nn); atomicAdd(&stats->ext_tris, nt); }
+        wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
+        wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
     }
 }
 
 // Shade stage of the unfused form.
 template <bool FIRST>
 __global__ __launch_bounds__(64) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
+                                              const uint32_t *__restrict__ samples,
                                               const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
                                               uint32_t n_slots, int max_depth) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.counters[4 * depth];
-    const uint32_t *__restrict__ q = b.q_ext[q_in];
+    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][blockIdx.x];
+    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)blockIdx.x * b.region_cap;
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
+    RouteFill fill;
+    fill.shadow = fill.glossy = fill.next = 0;
 
-    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+    for (uint32_t base = FIRST ? blockIdx.x * 64u : 0u; base < total; base += FIRST ? gridDim.x * 64u : 64u) {
         const uint32_t qi = base + lane;
         bool live = qi < total;
         uint32_t id = 0;
+        PathState ps;
         if (FIRST) {
+            // the camera ray is cheap to regenerate (raytracer.glsl:594-606): no state was stored for depth 0
             id = live ? qi : 0u;
-            const uint32_t tile = (id % paths_per_sample) >> 6;
+            const uint32_t slot = id / paths_per_sample;
+            const uint32_t tile = (id - slot * paths_per_sample) >> 6;
             const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
             const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
             live = live && (tx < fr.width) && (ty < fr.height);
+            ps.seed = pixel_seed(fr, tx, ty, samples[slot]);
+            const Ray cam = camera_ray(fr, tx, ty, ps.seed);
+            ps.o = cam.o; ps.d = cam.d;
+            ps.path = mk3(1.0f, 1.0f, 1.0f);
+            ps.energy = mk3(0.0f, 0.0f, 0.0f);
         } else {
             id = live ? q[qi] : 0u;
+            load_path(b, id, ps);
+            ps.seed = b.s3[id].x;
         }
-        PathState ps;
-        load_path(b, id, ps);
-        ps.seed = b.s3[id].x;
         const float4 h = b.h0[id];
         shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, __float_as_int(h.w),
-                        h.x, h.y, h.z);
+                        h.x, h.y, h.z, fill);
     }
+    store_route_fill(b, q_in, fill);
 }
 
-// Shadow-probe stage: occlusion loop of sampleLight (raytracer.glsl:372-378), then :557-579.
+// Shadow-probe stage: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579.
 template <bool BVH>
-__global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in, int max_depth,
-                                                     DStats *__restrict__ stats) {
+__global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in, int max_depth) {
     const uint32_t lane = threadIdx.x;
     __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
     int *stack = stack_mem + lane;
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
-    uint32_t *cnt = b.counters + 4 * depth;
-    uint32_t *cnt_next = b.counters + 4 * (depth + 1);
-    const uint32_t total = cnt[1];
-    uint32_t *q_next = b.q_ext[q_in ^ 1];
-    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+    const size_t region = (size_t)blockIdx.x * b.region_cap;
+    const uint32_t total = b.n_shadow[blockIdx.x];
+    uint32_t fill_next = b.n_ext[q_in ^ 1][blockIdx.x];
+    for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t qi = base + lane;
         const bool live = qi < total;
-        const uint32_t id = live ? b.q_shadow[qi] : 0u;
+        const uint32_t id = live ? b.q_shadow[region + qi] : 0u;
         const float4 a = b.s0[id], pr = b.p0[id];
         const uint2 sc3 = b.s3[id];
         Ray probe;
@@ -254,32 +279,32 @@ __global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuf
             b.s3[id] = make_uint2(ps.seed, sc3.y);
         }
         to_next = to_next && (depth + 1 < max_depth);
-        queue_push(q_next, cnt_next + 0, to_next, id);
+        region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next, id);
     }
-    if (blockIdx.x == 0 && lane == 0) atomicAdd(&stats->shadow_probes, (unsigned long long)total);
+    if (lane == 0) b.n_ext[q_in ^ 1][blockIdx.x] = fill_next;
+    wstat_add(b, WSTAT_SHADOW, total);
     if (BVH) {
-        const unsigned long long nn = wave_sum_u32(bc.nodes), nt = wave_sum_u32(bc.tris);
-        if (lane == 0 && (nn | nt)) { atomicAdd(&stats->probe_nodes, nn); atomicAdd(&stats->probe_tris, nt); }
+        wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
+        wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(bc.tris));
     }
 }
 
-// Glossy-probe stage: search loop of sampleLightGlossy (raytracer.glsl:403-437), then :557-579.
+// Glossy-probe stage: search of sampleLightGlossy (raytracer.glsl:403-437), then :557-579.
 template <bool BVH>
 __global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth,
-                                                     int q_in, int max_depth, DStats *__restrict__ stats) {
+                                                     int q_in, int max_depth) {
     const uint32_t lane = threadIdx.x;
     __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
     int *stack = stack_mem + lane;
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
-    uint32_t *cnt = b.counters + 4 * depth;
-    uint32_t *cnt_next = b.counters + 4 * (depth + 1);
-    const uint32_t total = cnt[2];
-    uint32_t *q_next = b.q_ext[q_in ^ 1];
-    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+    const size_t region = (size_t)blockIdx.x * b.region_cap;
+    const uint32_t total = b.n_glossy[blockIdx.x];
+    uint32_t fill_next = b.n_ext[q_in ^ 1][blockIdx.x];
+    for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t qi = base + lane;
         const bool live = qi < total;
-        const uint32_t id = live ? b.q_glossy[qi] : 0u;
+        const uint32_t id = live ? b.q_glossy[region + qi] : 0u;
         const float4 a = b.s0[id], pr = b.p0[id];
         const uint2 sc3 = b.s3[id];
         Ray probe;
@@ -306,13 +331,25 @@ __global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DBvh bv, DBvh lb
             b.s3[id] = make_uint2(ps.seed, sc3.y);
         }
         to_next = to_next && (depth + 1 < max_depth);
-        queue_push(q_next, cnt_next + 0, to_next, id);
+        region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next, id);
     }
-    if (blockIdx.x == 0 && lane == 0) atomicAdd(&stats->glossy_probes, (unsigned long long)total);
+    if (lane == 0) b.n_ext[q_in ^ 1][blockIdx.x] = fill_next;
+    wstat_add(b, WSTAT_GLOSSY, total);
     if (BVH) {
-        const unsigned long long nn = wave_sum_u32(bc.nodes), nt = wave_sum_u32(bc.tris);
-        if (lane == 0 && (nn | nt)) { atomicAdd(&stats->probe_nodes, nn); atomicAdd(&stats->probe_tris, nt); }
+        wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
+        wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(bc.tris));
     }
+}
+
+// Sum of one array of region fill counts (for the host's early stop).
+__global__ __launch_bounds__(256) void k_sum_counts(const uint32_t *__restrict__ counts, int n, uint32_t *__restrict__ out) {
+    __shared__ uint32_t part[4];
+    uint32_t v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += counts[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = part[0] + part[1] + part[2] + part[3];
 }
 
 // Resolve stage: sum[pixel] += energy of the batch's samples, ascending slot order.
@@ -335,7 +372,6 @@ __global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restri
 struct Pipeline {
     PipeBuffers buf = {};
     size_t cap_paths = 0;
-    int cap_depth = 0;
     uint32_t *d_coins = nullptr;
     size_t cap_coins = 0;
     uint32_t *h_count = nullptr;   // pinned, for the early-stop read-back
@@ -344,12 +380,23 @@ struct Pipeline {
     std::vector<hipEvent_t> events;
     std::vector<int> kinds;        // interval i = [event i, event i+1]: 0 extend, 3 extend at depth 0, 1 probes, 2 shade, -1 not counted
     size_t ev_used = 0;
+    // light seeds are also needed on the host to tabulate the per-depth coin; set before run()
+    std::vector<uint32_t> h_light_seeds;
 
-    void release() {
+    void free_paths() {
         (void)hipFree(buf.s0); (void)hipFree(buf.s1); (void)hipFree(buf.s2); (void)hipFree(buf.s3);
         (void)hipFree(buf.p0); (void)hipFree(buf.p1); (void)hipFree(buf.h0);
         (void)hipFree(buf.q_ext[0]); (void)hipFree(buf.q_ext[1]); (void)hipFree(buf.q_shadow); (void)hipFree(buf.q_glossy);
-        (void)hipFree(buf.counters);
+        buf.s0 = buf.s1 = buf.s2 = buf.p0 = buf.p1 = buf.h0 = nullptr;
+        buf.s3 = nullptr;
+        buf.q_ext[0] = buf.q_ext[1] = buf.q_shadow = buf.q_glossy = nullptr;
+        cap_paths = 0;
+    }
+
+    void release() {
+        free_paths();
+        (void)hipFree(buf.n_ext[0]); (void)hipFree(buf.n_ext[1]); (void)hipFree(buf.n_shadow); (void)hipFree(buf.n_glossy);
+        (void)hipFree(buf.wstats); (void)hipFree(buf.total);
         (void)hipFree(d_coins);
         if (h_count) (void)hipHostFree(h_count);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -357,19 +404,31 @@ struct Pipeline {
         buf = PipeBuffers{};
         d_coins = nullptr;
         h_count = nullptr;
-        cap_paths = 0; cap_depth = 0; cap_coins = 0;
+        cap_coins = 0;
     }
 
-    hipError_t ensure(size_t paths, int depth, size_t coins, const char **what) {
+    static uint32_t region_cap_for(size_t paths) {
+        const size_t chunks = (paths + 63) / 64;
+        return (uint32_t)(((chunks + PIPE_WAVES - 1) / PIPE_WAVES) * 64);
+    }
+
+    hipError_t ensure(size_t paths, size_t coins, const char **what) {
         hipError_t e = hipSuccess;
 #define PIPE_ALLOC(ptr, bytes) do { *what = #ptr; e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
+        if (!buf.wstats) {
+            PIPE_ALLOC(buf.wstats, sizeof(unsigned long long) * 8 * PIPE_WAVES);
+            *what = "memset wstats";
+            e = hipMemset(buf.wstats, 0, sizeof(unsigned long long) * 8 * PIPE_WAVES);
+            if (e != hipSuccess) return e;
+            PIPE_ALLOC(buf.n_ext[0], sizeof(uint32_t) * PIPE_WAVES);
+            PIPE_ALLOC(buf.n_ext[1], sizeof(uint32_t) * PIPE_WAVES);
+            PIPE_ALLOC(buf.n_shadow, sizeof(uint32_t) * PIPE_WAVES);
+            PIPE_ALLOC(buf.n_glossy, sizeof(uint32_t) * PIPE_WAVES);
+            PIPE_ALLOC(buf.total, sizeof(uint32_t) * 4);
+        }
         if (paths > cap_paths) {
-            (void)hipFree(buf.s0); (void)hipFree(buf.s1); (void)hipFree(buf.s2); (void)hipFree(buf.s3);
-            (void)hipFree(buf.p0); (void)hipFree(buf.p1); (void)hipFree(buf.h0);
-            (void)hipFree(buf.q_ext[0]); (void)hipFree(buf.q_ext[1]); (void)hipFree(buf.q_shadow); (void)hipFree(buf.q_glossy);
-            buf.s0 = buf.s1 = buf.s2 = buf.p0 = buf.p1 = buf.h0 = nullptr; buf.s3 = nullptr;
-            buf.q_ext[0] = buf.q_ext[1] = buf.q_shadow = buf.q_glossy = nullptr;
-            cap_paths = 0;
+            free_paths();
+            const size_t qn = (size_t)region_cap_for(paths) * PIPE_WAVES;
             PIPE_ALLOC(buf.s0, sizeof(float4) * paths);
             PIPE_ALLOC(buf.s1, sizeof(float4) * paths);
             PIPE_ALLOC(buf.s2, sizeof(float4) * paths);
@@ -377,18 +436,11 @@ struct Pipeline {
             PIPE_ALLOC(buf.p0, sizeof(float4) * paths);
             PIPE_ALLOC(buf.p1, sizeof(float4) * paths);
             PIPE_ALLOC(buf.h0, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.q_ext[0], sizeof(uint32_t) * paths);
-            PIPE_ALLOC(buf.q_ext[1], sizeof(uint32_t) * paths);
-            PIPE_ALLOC(buf.q_shadow, sizeof(uint32_t) * paths);
-            PIPE_ALLOC(buf.q_glossy, sizeof(uint32_t) * paths);
+            PIPE_ALLOC(buf.q_ext[0], sizeof(uint32_t) * qn);
+            PIPE_ALLOC(buf.q_ext[1], sizeof(uint32_t) * qn);
+            PIPE_ALLOC(buf.q_shadow, sizeof(uint32_t) * qn);
+            PIPE_ALLOC(buf.q_glossy, sizeof(uint32_t) * qn);
             cap_paths = paths;
-        }
-        if (depth > cap_depth) {
-            (void)hipFree(buf.counters);
-            buf.counters = nullptr;
-            cap_depth = 0;
-            PIPE_ALLOC(buf.counters, sizeof(uint32_t) * 4 * (size_t)(depth + 2));
-            cap_depth = depth;
         }
         if (coins > cap_coins) {
             (void)hipFree(d_coins);
@@ -405,11 +457,6 @@ struct Pipeline {
 #undef PIPE_ALLOC
         return hipSuccess;
     }
-
-    // Renders the `n` samples listed in d_samples (light seeds in h_light_seeds order) and adds them to `sum`.
-    hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
-                   const uint32_t *d_light_seeds, int n, DStats *d_stats, hipStream_t stream, bool profiling,
-                   bool fused, rt_stats *host_stats, const char **what);
 
     // Adds the time of every recorded interval to host_stats and recycles the events.
     hipError_t collect_times(rt_stats *host_stats) {
@@ -438,22 +485,39 @@ struct Pipeline {
         return e;
     }
 
-    // light seeds are also needed on the host to tabulate the per-depth coin; set before run()
-    std::vector<uint32_t> h_light_seeds;
+    // Sums the per-wave work counters into `out` (8 values, WSTAT_* order); synchronous.
+    hipError_t read_wstats(unsigned long long out[8]) {
+        for (int k = 0; k < 8; k++) out[k] = 0;
+        if (!buf.wstats) return hipSuccess;
+        std::vector<unsigned long long> h((size_t)8 * PIPE_WAVES);
+        hipError_t e = hipMemcpy(h.data(), buf.wstats, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        for (size_t i = 0; i < h.size(); i++) out[i & 7] += h[i];
+        return hipSuccess;
+    }
+    hipError_t reset_wstats(hipStream_t stream) {
+        if (!buf.wstats) return hipSuccess;
+        return hipMemsetAsync(buf.wstats, 0, sizeof(unsigned long long) * 8 * PIPE_WAVES, stream);
+    }
+
+    // Renders the `n` samples listed in d_samples and adds them to `sum`.
+    hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
+                   const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, rt_stats *host_stats,
+                   const char **what);
 };
 
-inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum, const uint32_t *d_samples,
-                                const uint32_t *d_light_seeds, int n, DStats *d_stats, hipStream_t stream,
-                                bool profiling, bool fused, rt_stats *host_stats, const char **what) {
-    (void)d_light_seeds;
+inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
+                                const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused,
+                                rt_stats *host_stats, const char **what) {
     const bool use_bvh = bvh.enabled != 0;
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
     const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
     const uint32_t pps = tiles * 64u;
     const size_t paths = (size_t)pps * (size_t)n;
     if (paths > 0xFFFFFFF0ull) { *what = "batch has more than 2^32 paths"; return hipErrorInvalidValue; }
-    hipError_t e = ensure(paths, max_depth, (size_t)n * max_depth, what);
+    hipError_t e = ensure(paths, (size_t)n * max_depth, what);
     if (e != hipSuccess) return e;
+    buf.region_cap = region_cap_for(paths);
 
     // coin[slot][depth] = unitFloat(light_seed) < 0.5 after `depth` earlier draws (raytracer.glsl:553)
     std::vector<uint32_t> coins((size_t)n * max_depth);
@@ -469,7 +533,6 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
 #define PIPE_TRY(expr) do { *what = #expr; e = (expr); if (e != hipSuccess) return e; } while (0)
     PIPE_TRY(hipMemcpyAsync(d_coins, coins.data(), sizeof(uint32_t) * coins.size(), hipMemcpyHostToDevice, stream));
     PIPE_TRY(hipStreamSynchronize(stream));   // `coins` is a local
-    PIPE_TRY(hipMemsetAsync(buf.counters, 0, sizeof(uint32_t) * 4 * (size_t)(max_depth + 2), stream));
 
     if (profiling && ev_used > 8192) PIPE_TRY(collect_times(host_stats));
     auto stamp = [&](int kind_of_next_interval) -> hipError_t {
@@ -484,50 +547,49 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         return hipEventRecord(events[ev_used++], stream);
     };
 
-    const uint32_t chunks0 = (uint32_t)((paths + 63) / 64);
-    const dim3 grid0(chunks0 < (uint32_t)PIPE_WAVES ? chunks0 : (uint32_t)PIPE_WAVES), grid(PIPE_WAVES), block(64);
+    const dim3 grid(PIPE_WAVES), block(64);
     int q_in = 0;
     for (int depth = 0; depth < max_depth; depth++) {
         PIPE_TRY(stamp(depth == 0 ? 3 : 0));
-#define LAUNCH_EXTEND(F, FU, BV, G)                                                                              \
-    hipLaunchKernelGGL((k_extend<F, FU, BV>), G, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples, d_coins, \
-                       pps, (uint32_t)n, max_depth, d_stats)
+#define LAUNCH_EXTEND(F, FU, BV)                                                                                        \
+    hipLaunchKernelGGL((k_extend<F, FU, BV>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples, d_coins, \
+                       pps, (uint32_t)n, max_depth)
         if (fused) {
-            if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, true, true, grid0); else LAUNCH_EXTEND(true, true, false, grid0); }
-            else { if (use_bvh) LAUNCH_EXTEND(false, true, true, grid); else LAUNCH_EXTEND(false, true, false, grid); }
+            if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, true, true); else LAUNCH_EXTEND(true, true, false); }
+            else { if (use_bvh) LAUNCH_EXTEND(false, true, true); else LAUNCH_EXTEND(false, true, false); }
             PIPE_TRY(hipGetLastError());
         } else {
-            if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, false, true, grid0); else LAUNCH_EXTEND(true, false, false, grid0); }
-            else { if (use_bvh) LAUNCH_EXTEND(false, false, true, grid); else LAUNCH_EXTEND(false, false, false, grid); }
+            if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, false, true); else LAUNCH_EXTEND(true, false, false); }
+            else { if (use_bvh) LAUNCH_EXTEND(false, false, true); else LAUNCH_EXTEND(false, false, false); }
             PIPE_TRY(hipGetLastError());
             PIPE_TRY(stamp(2));
             if (depth == 0)
-                hipLaunchKernelGGL(k_shade<true>, grid0, block, 0, stream, sc, fr, buf, depth, q_in, d_coins, pps,
-                                   (uint32_t)n, max_depth);
+                hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins,
+                                   pps, (uint32_t)n, max_depth);
             else
-                hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_coins, pps,
-                                   (uint32_t)n, max_depth);
+                hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins,
+                                   pps, (uint32_t)n, max_depth);
             PIPE_TRY(hipGetLastError());
         }
 #undef LAUNCH_EXTEND
         PIPE_TRY(stamp(1));
         if (use_bvh) {
-            hipLaunchKernelGGL(k_probe_shadow<true>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth, d_stats);
+            hipLaunchKernelGGL(k_probe_shadow<true>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
             PIPE_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_probe_glossy<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
-                               max_depth, d_stats);
+            hipLaunchKernelGGL(k_probe_glossy<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
         } else {
-            hipLaunchKernelGGL(k_probe_shadow<false>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth, d_stats);
+            hipLaunchKernelGGL(k_probe_shadow<false>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
             PIPE_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_probe_glossy<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
-                               max_depth, d_stats);
+            hipLaunchKernelGGL(k_probe_glossy<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
         }
         PIPE_TRY(hipGetLastError());
         PIPE_TRY(stamp(-1));
         q_in ^= 1;
         // deep paths are rare: from depth 4 on, stop as soon as the next extend queue is empty
         if (depth >= 3 && depth + 1 < max_depth) {
-            PIPE_TRY(hipMemcpyAsync(h_count, buf.counters + 4 * (depth + 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(256), 0, stream, buf.n_ext[q_in], PIPE_WAVES, buf.total);
+            PIPE_TRY(hipGetLastError());
+            PIPE_TRY(hipMemcpyAsync(h_count, buf.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             PIPE_TRY(hipStreamSynchronize(stream));
             if (h_count[0] == 0) break;
         }
@@ -535,7 +597,6 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
     hipLaunchKernelGGL(k_resolve, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
                        fr.height, pps, (uint32_t)n);
     PIPE_TRY(hipGetLastError());
-
 #undef PIPE_TRY
     return hipSuccess;
 }
