@@ -58,7 +58,7 @@ struct rt_context {
 
     // options
     int pipeline = 1;
-    int batch_samples = 4;
+    int batch_samples = 16;
     int profiling = 0;
     int fuse_shade = 1;
 

@@ -37,7 +37,7 @@ namespace rt {
 
 struct DBvh {
     const float4 *nodes;     // 4 x float4 per node
-    const float4 *leaf_geo;  // 3 x float4 per leaf slot
+    const float4 *leaf_geo;  // 4 x float4 per leaf slot: triangle record + (index, -, -, -)
     const int *leaf_ids;
     float max_abs_coord;
     int enabled;
@@ -59,7 +59,8 @@ RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
     const float r = m * (1.0f / 65536.0f) + 1e-30f;
     b.o_lo = mk3(ray.o.x - r, ray.o.y - r, ray.o.z - r);
     b.o_hi = mk3(ray.o.x + r, ray.o.y + r, ray.o.z + r);
-    b.inv = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    // reciprocal to 1 ulp: the slab test is conservative by far more than that
+    b.inv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
     const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
     b.finite = (s - s) == 0.0f;      // false when any component is NaN or infinite
     return b;
@@ -92,9 +93,12 @@ RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, int *sta
     int sp = 0;
     int node = 0;
     bool run = active;
+    // "while-while" order: all lanes first descend through inner nodes until each holds a leaf (or has
+    // finished), then all leaves are processed together; this keeps box tests and triangle tests of a
+    // wave from interleaving lane by lane.
     while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-        if (run) {
-            if (node >= 0) {
+        while (__builtin_amdgcn_ballot_w64(run && node >= 0) != 0ull) {
+            if (run && node >= 0) {
                 const float4 q0 = bv.nodes[4 * node + 0], q1 = bv.nodes[4 * node + 1], q2 = bv.nodes[4 * node + 2],
                              q3 = bv.nodes[4 * node + 3];
                 cnt.nodes++;
@@ -116,27 +120,30 @@ RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, int *sta
                 } else {
                     run = false;
                 }
+            }
+        }
+        if (run) {      // node < 0: a leaf
+            const int code = ~node;
+            const int first = code >> 3, n = code & 7;
+            bool go_on = true;
+            for (int k = 0; k < n; k++) {
+                cnt.tris++;
+                if (go_on) go_on = leaf(first + k);
+            }
+            if (go_on && sp > 0) {
+                sp--;
+                node = stack[64 * sp];
             } else {
-                const int code = ~node;
-                const int first = code >> 3, n = code & 7;
-                bool go_on = true;
-                for (int k = 0; k < n; k++) {
-                    cnt.tris++;
-                    if (go_on) go_on = leaf(first + k);
-                }
-                if (go_on && sp > 0) {
-                    sp--;
-                    node = stack[64 * sp];
-                } else {
-                    run = false;
-                }
+                run = false;
             }
         }
     }
 }
 
-RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot) {
-    const float4 a = bv.leaf_geo[3 * slot + 0], b = bv.leaf_geo[3 * slot + 1], c = bv.leaf_geo[3 * slot + 2];
+RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot, int &id) {
+    const float4 a = bv.leaf_geo[4 * slot + 0], b = bv.leaf_geo[4 * slot + 1], c = bv.leaf_geo[4 * slot + 2],
+                 d = bv.leaf_geo[4 * slot + 3];
+    id = __float_as_int(d.x);
     Tri t;
     t.n = mk3(a.x, a.y, a.z);
     t.p = mk3(a.w, b.x, b.y);
@@ -158,9 +165,9 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
     f4 st;
     st.x = 0.0f; st.y = 0.0f; st.z = -1.0f; st.w = w_init;
     auto leaf = [&](int slot) -> bool {
-        const int id = bv.leaf_ids[slot];
+        int id;
+        const Tri t = load_leaf_tri(bv, slot, id);
         if (id < begin_id || id >= end_id || id == current) return true;
-        const Tri t = load_leaf_tri(bv, slot);
         const float det = -dot(ray.d, t.n);
         const f3 delta = ray.o - t.p;
         const float rd = dot(t.n, delta);
@@ -174,7 +181,7 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
         if (best < 0) take = true;
         else if (id > best) take = !(rd * st.w > st.z * det);
         else take = (st.z * det > rd * st.w);
-        const float tc = rd / det;
+        const float tc = rd * __builtin_amdgcn_rcpf(det);     // pruning only: 1 ulp is far inside the margin
         if (tc * BVH_NEAR < t_min) n_near = 1;
         else if (tc <= t_min * BVH_NEAR) n_near++;
         t_min = __builtin_fminf(t_min, tc);
@@ -205,9 +212,9 @@ RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
     const bool ok = br.finite && ((max_t - max_t) == 0.0f);
     bool blocked = false;
     auto leaf = [&](int slot) -> bool {
-        const int id = bv.leaf_ids[slot];
+        int id;
+        const Tri t = load_leaf_tri(bv, slot, id);
         if (id == current) return true;
-        const Tri t = load_leaf_tri(bv, slot);
         if (intersect_triangle_shadow(ray, t, max_t)) { blocked = true; return false; }
         return true;
     };
@@ -233,9 +240,9 @@ RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
     bool blocked = false;
     const int lights = sc.lights;
     auto leaf = [&](int slot) -> bool {
-        const int id = bv.leaf_ids[slot];
+        int id;
+        const Tri t = load_leaf_tri(bv, slot, id);
         if (id < lights || id == current) return true;
-        const Tri t = load_leaf_tri(bv, slot);
         PlaneTest pt;
         float rx, ry;
         if (plane_test_closest(ray, t, isec, pt) && inside_test(ray, t, pt, rx, ry)) { blocked = true; return false; }

@@ -9,8 +9,8 @@
 // Layout handed to the device:
 //   nodes   4 x float4 per inner node:  (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (c0, c1, -, -)
 //           child >= 0: inner node index;  child < 0: leaf, ~child = (first << 3) | count, count <= 4
-//   leaves  triangle records (3 x float4, the TriangleModel layout) in leaf order, and their
-//           original triangle index
+//   leaves  one 64-byte record per triangle in leaf order: 3 x float4 in the TriangleModel layout, then
+//           (original triangle index, -, -, -)
 // Boxes are padded by a few ulps of their largest coordinate so that float rounding of p + u, p + v
 // can never put a vertex outside its box.
 #pragma once
@@ -27,7 +27,7 @@ namespace rt {
 
 struct HostBvh {
     std::vector<float> nodes;          // 16 floats per node
-    std::vector<float> leaf_geo;       // 12 floats per leaf slot
+    std::vector<float> leaf_geo;       // 16 floats per leaf slot: the 12 of the triangle record, its index, padding
     std::vector<int32_t> leaf_ids;     // original triangle index per leaf slot
     int depth = 0;
     float max_abs_coord = 0.0f;        // largest |coordinate| of any vertex
@@ -48,7 +48,10 @@ struct Box {
 
 struct Item { Box box; float c[3]; int32_t id; };
 
-constexpr int MAX_LEAF = 4;
+#ifndef RT_MAX_LEAF
+#define RT_MAX_LEAF 4
+#endif
+constexpr int MAX_LEAF = RT_MAX_LEAF;
 constexpr int BINS = 16;
 
 }  // namespace bvh_detail
@@ -100,6 +103,10 @@ inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool f
             const rt_triangle_model &t = tris[items[i].id];
             const float *src = (const float *)&t;
             out.leaf_geo.insert(out.leaf_geo.end(), src, src + 12);
+            float idbits;
+            memcpy(&idbits, &items[i].id, 4);
+            out.leaf_geo.push_back(idbits);
+            out.leaf_geo.insert(out.leaf_geo.end(), 3, 0.0f);
             out.leaf_ids.push_back(items[i].id);
         }
         return ~(int32_t)((first << 3) | (end - begin));
