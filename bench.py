@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--fuse-shade", type=int, default=1)
     ap.add_argument("--accel", type=int, default=-1, help="-1 auto, 0 loops over all triangles, 1 hierarchy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +87,7 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:     # under torch.distributed.run also with one rank (exercises the RCCL path)
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -152,10 +153,29 @@ def main():
         # samples poison their pixel in the reference too, and are reproduced here
         nonfinite_pixels = int((~finite).sum().item())
         mean = img[finite].mean().item()
-        # dominant kernel: the depth-0 closest-hit launches (one camera ray per pixel-sample)
+        # largest kernel: the depth-0 extend launches (closest hit of one camera ray per pixel-sample + shading)
         ext_ms, ext_n = st["extend0_ms"], max(1, st["extend0_launches"])
-        flops = float(st["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
-        achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
+        used_bvh = st["bvh_extend_nodes"] > 0
+        if used_bvh:
+            # Hierarchy traversal: nodes and triangles come from L1/L2 (the scene is 60 KB); what has to cross
+            # HBM is the path state the stage leaves behind: ray/throughput/radiance 48 B + seed/triangle 8 B +
+            # probe record 32 B + queue entry 4 B per camera path.
+            bytes_per_path = 92.0
+            algo = float(st["pixel_samples"]) * bytes_per_path
+            achieved = algo / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": "k_extend<FIRST,FUSED,BVH> (depth-0 closest hit by hierarchy + shading)",
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "traffic": None, "bytes_per_launch": algo / ext_n,
+                    "note": "latency/issue bound: 10 node visits + 6 triangle tests per ray, see profiles/"}
+        else:
+            flops = float(st["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
+            achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
+            roof = {"bound": "valu", "kernel": "k_extend<FIRST,FUSED> (depth-0 loop over all triangles + shading)",
+                    "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None, "flops_per_launch": flops / ext_n}
+        roof.update({"avg_launch_ms": ext_ms / ext_n, "launches": int(st["extend0_launches"]),
+                     "probe_kernels_ms": st["probe_ms"], "extend_kernels_ms": st["extend_ms"],
+                     "shade_kernels_ms": st["shade_ms"]})
         out = {
             "metric": "Mrays/s (paths x bounces) at 1080p",
             "value": rays / dt / 1e6,
@@ -168,8 +188,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "cubes 424 tris, 1920x1080, RECURSION 6, %d spp per GPU (%d spp/step), "
-                                   "constant environment, brute-force closest hit" % (args.steps * spp, spp),
+                                   "constant environment" % (args.steps * spp, spp),
                        "pipeline": "staged" if args.pipeline else "single-kernel",
+                       "closest_hit": "hierarchy (exact)" if used_bvh else "loop over all triangles",
                        "parallelism": "spp split x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
             "seconds_to_%dspp" % (args.steps * spp): dt,
             "probe_rays_per_s_M": probes / dt / 1e6,
@@ -177,16 +198,28 @@ def main():
             "mean_radiance": mean,
             "nonfinite_pixels": nonfinite_pixels,
             "bvh": {k: st[k] for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris")},
-            "roofline": {
-                "bound": "valu", "kernel": "k_extend<FIRST> (depth-0 brute-force closest hit + shading)",
-                "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_VALU_TFLOPS,
-                "traffic": None,
-                "avg_launch_ms": ext_ms / ext_n, "launches": int(st["extend0_launches"]),
-                "flops_per_launch": flops / ext_n,
-                "probe_kernels_ms": st["probe_ms"], "extend_kernels_ms": st["extend_ms"], "shade_kernels_ms": st["shade_ms"],
-            },
+            "roofline": roof,
         }
+        if world == 1 and used_bvh and not args.no_bruteforce_pass:
+            # the reference's own algorithm (loop over all COUNT triangles per query) on the same GPU, short pass
+            ctx.set_option("accel", 0)
+            ctx.set_option("batch_samples", 4)
+            sums.zero_()
+            ctx.reset_stats()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.trace(0, 64, 1)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            s1 = ctx.stats()
+            f1 = float(s1["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
+            a1 = f1 / (s1["extend0_ms"] * 1e-3) / 1e12 if s1["extend0_ms"] > 0 else 0.0
+            out["roofline_bruteforce"] = {
+                "bound": "valu", "kernel": "k_extend<FIRST,FUSED> (depth-0 loop over all 424 triangles + shading)",
+                "achieved": a1, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": a1 / PEAK_VALU_TFLOPS,
+                "avg_launch_ms": s1["extend0_ms"] / max(1, s1["extend0_launches"]),
+                "flops_per_launch": f1 / max(1, s1["extend0_launches"]),
+                "value_Mrays_per_s": s1["rays"] / dt1 / 1e6, "sample": "64 spp"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, clock)
         print(json.dumps(out))
