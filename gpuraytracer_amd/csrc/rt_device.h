@@ -1,11 +1,14 @@
 // rt_device.h - device-side building blocks of the gfx950 path tracer.
 //
-// Arithmetic contract: every value that can influence a hit decision or a random
-// branch is computed in IEEE float32 with separate multiplies and adds (the translation
-// unit is compiled with -ffp-contract=off), dot products are summed in the order fixed by
-// RT_DOT_ORDER, divisions and square roots are correctly rounded, and the elementary
-// functions come from rt_detmath.h.  Under that contract the device reproduces a host
-// evaluation of the same formulas bit for bit.
+// Arithmetic contract: IEEE float32 with separate multiplies and adds (the translation unit is
+// compiled with -ffp-contract=off), correctly rounded divisions and square roots, denormals kept.
+// Where GLSL leaves a choice to the GL implementation, the choice is the one Mesa 23.2 (llvmpipe)
+// makes when it compiles the reference's shader, because that is the implementation under which
+// the unmodified shader can be executed and compared with: dot products are summed from the last
+// component to the first, fma() is a separate multiply and add, and the elementary functions and
+// the bilinear texture filter are those of rt_glslmath.h / bilinear_mix below.  Under that contract
+// the device reproduces the llvmpipe run of the reference shader bit for bit.  Comments starting
+// with "Mesa:" mark these choices.
 //
 // Each function names the lines of the reference shader (res/shader/raytracer.glsl) whose
 // behaviour it implements.
@@ -14,10 +17,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "rt_detmath.h"
+#include "rt_glslmath.h"
 
 #ifndef RT_DOT_ORDER
-#define RT_DOT_ORDER 0   // 0: (x*x' + y*y') + z*z'    1: (z*z' + y*y') + x*x'
+#define RT_DOT_ORDER 1   // 0: (x*x' + y*y') + z*z'    1: (z*z' + y*y') + x*x'  (Mesa)
 #endif
 
 #define RT_DEV __device__ __forceinline__
@@ -52,10 +55,10 @@ RT_DEV f3 reflect(f3 I, f3 N) {
     const float k = 2.0f * dot(N, I);
     return I - N * k;
 }
-RT_DEV float gmax(float x, float y) { return (x < y) ? y : x; }
-RT_DEV float gmin(float x, float y) { return (y < x) ? y : x; }
+// Mesa: max/min are IEEE maxNum/minNum (a NaN operand yields the other operand)
+RT_DEV float gmax(float x, float y) { return __builtin_fmaxf(x, y); }
+RT_DEV float gmin(float x, float y) { return __builtin_fminf(x, y); }
 RT_DEV float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
-RT_DEV float pow5(float x) { const float x2 = x * x; return (x2 * x2) * x; }
 
 constexpr float TWO_PI_F = 6.283185307179586f;
 constexpr float INV_PI_F = (float)(1.0 / 3.141592653589793);
@@ -108,7 +111,7 @@ RT_DEV f3 random_sphere(uint32_t &seed) {          // :100-113
     const float x = unit_float(seed) * 2.0f - 1.0f;
     const float sinx = __builtin_sqrtf(1.0f - x * x);
     float s, c;
-    dm::sincos(theta, s, c);
+    gm::sincos(theta, s, c);
     return mk3(sinx * c, sinx * s, x);
 }
 
@@ -252,27 +255,40 @@ RT_DEV f3 unpack_r11g11b10(uint32_t p) {
 
 struct Bilinear { int i0, i1, j0, j1; float a, b; };
 
-// LINEAR filtering with REPEAT wrap: x = s*W - 0.5, i0 = floor(x), a = x - i0.
+// LINEAR filtering with REPEAT wrap.  Mesa (llvmpipe), per axis of length L:
+//   L a power of two:  x = c*L - 0.5;  i = floor(x);  texels i & (L-1), (i+1) & (L-1)
+//   otherwise:         c = c - floor(c);  x = c*L - 0.5;  i = floor(x);  texels (x < 0 ? L-1 : i), (i+1 == L ? 0 : i+1)
+//   weight w = x - floor(x);  lerp(w, v0, v1) = fma(w, v1 - v0, v0), along s for both rows, then along t.
+// A coordinate whose texel index does not fit an int (NaN included) uses index 0; its weight follows
+// from the same arithmetic (NaN for NaN and infinities, which makes the sample NaN).
+RT_DEV void wrap_repeat_linear(float c, int L, int &i0, int &i1, float &w) {
+    const bool pot = (L & (L - 1)) == 0;
+    if (!pot) c = c - __builtin_floorf(c);
+    const float x = c * (float)L - 0.5f;
+    const float fl = __builtin_floorf(x);
+    w = x - fl;
+    const bool in_range = __builtin_fabsf(fl) < 2147483648.0f;
+    const int i = in_range ? (int)fl : 0;
+    if (pot) {
+        i0 = i & (L - 1);
+        i1 = (i + 1) & (L - 1);
+    } else {
+        i0 = (x < 0.0f) ? L - 1 : i;
+        i1 = (i + 1 >= L) ? 0 : i + 1;
+        if (!in_range || i0 >= L) { i0 = 0; i1 = 0; }
+    }
+}
 RT_DEV Bilinear bilinear_setup(float s, float t, int W, int H) {
-    float x = s * (float)W - 0.5f, y = t * (float)H - 0.5f;
-    if (!(__builtin_fabsf(x) < 1073741824.0f)) x = 0.0f;
-    if (!(__builtin_fabsf(y) < 1073741824.0f)) y = 0.0f;
-    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
     Bilinear bl;
-    bl.a = x - fx;
-    bl.b = y - fy;
-    const int ix = (int)fx, iy = (int)fy;
-    bl.i0 = ((ix % W) + W) % W;
-    bl.i1 = (((ix + 1) % W) + W) % W;
-    bl.j0 = ((iy % H) + H) % H;
-    bl.j1 = (((iy + 1) % H) + H) % H;
+    wrap_repeat_linear(s, W, bl.i0, bl.i1, bl.a);
+    wrap_repeat_linear(t, H, bl.j0, bl.j1, bl.b);
     return bl;
 }
+RT_DEV float lerp1(float w, float v0, float v1) { return __builtin_fmaf(w, v1 - v0, v0); }
 RT_DEV f3 bilinear_mix(f3 t00, f3 t10, f3 t01, f3 t11, float a, float b) {
-    const float ia = 1.0f - a, ib = 1.0f - b;
-    const f3 top = t00 * ia + t10 * a;
-    const f3 bot = t01 * ia + t11 * a;
-    return top * ib + bot * b;
+    const f3 top = mk3(lerp1(a, t00.x, t10.x), lerp1(a, t00.y, t10.y), lerp1(a, t00.z, t10.z));
+    const f3 bot = mk3(lerp1(a, t01.x, t11.x), lerp1(a, t01.y, t11.y), lerp1(a, t01.z, t11.z));
+    return mk3(lerp1(b, top.x, bot.x), lerp1(b, top.y, bot.y), lerp1(b, top.z, bot.z));
 }
 
 RT_DEV f3 sample_env(const DScene &sc, float s, float t) {
@@ -296,8 +312,8 @@ RT_DEV f3 sample_atlas(const DScene &sc, float s, float t, uint32_t layer) {
 
 // skyColor, raytracer.glsl:273-276
 RT_DEV f3 sky_color(const DScene &sc, const DFrame &fr, f3 dir) {
-    const float s = dm::atan2(dir.z, dir.x) * INV_PI_F * 0.5f + 0.5f;
-    const float t = -dm::asin(dir.y) * INV_PI_F + 0.5f;
+    const float s = gm::atan2(dir.z, dir.x) * INV_PI_F * 0.5f + 0.5f;
+    const float t = -gm::asin(dir.y) * INV_PI_F + 0.5f;
     return sample_env(sc, s, t) * fr.exposure;
 }
 
@@ -309,7 +325,11 @@ RT_DEV float get_transmission(float cosThetaI, float etaI, float etaT) {
     const float cosThetaT = __builtin_sqrtf(1.0f - sinThetaT * sinThetaT);
     const float r0 = (etaT * cosThetaI - etaI * cosThetaT) / (etaT * cosThetaI + etaI * cosThetaT);
     const float r1 = (etaI * cosThetaI - etaT * cosThetaT) / (etaI * cosThetaI + etaT * cosThetaT);
+#if RT_DOT_ORDER == 0
     return (r0 * r0 + r1 * r1) * 0.5f;
+#else
+    return (r1 * r1 + r0 * r0) * 0.5f;
+#endif
 }
 
 // ---------------------------------------------------------------- camera, raytracer.glsl:586-607
@@ -357,11 +377,18 @@ RT_DEV Ray camera_ray(const DFrame &fr, uint32_t tx, uint32_t ty, uint32_t &seed
 
 enum ProbeKind : int { PROBE_NONE = 0, PROBE_SHADOW = 1, PROBE_GLOSSY = 2 };
 
+// The shader's sampleLight / sampleLightGlossy leave their `out vec3 light` unwritten when they return
+// false (raytracer.glsl:333-334, :369-370, :376-377, :420-425), yet the value still reaches
+// global_light (:557) and through it the Russian-roulette brightness (:575).  Mesa: after inlining,
+// each of the two functions keeps one `light` variable for the whole pixel-sample, so an unwritten
+// result is the value that function wrote at an earlier depth (zero before its first write).
+// kept_diff / kept_spec are those two variables.
 struct PathState {
     f3 o, d;          // current ray
     f3 path;          // throughput
     f3 energy;        // radiance gathered so far
     uint32_t seed;
+    f3 kept_diff, kept_spec;
 };
 
 struct Bounce {
@@ -369,11 +396,24 @@ struct Bounce {
     int current;      // triangle the path sits on
     f3 probe_d;       // probe ray direction (origin = PathState::o after shade_pre)
     float max_t;      // shadow probes: distance to the sampled light point
-    // shadow probes: c = the light term global_light would have if unoccluded, w unused
-    // glossy probes: c = specular colour, w = fresnel_reflectance + 1 - roughness
+    // coin = sampleLight: lit = the light the call returns if nothing occludes; albedo and roughness
+    //                     are the factors of global_light (:557)
+    // coin = sampleLightGlossy: c = specular colour, w = fresnel_reflectance + 1 - roughness
+    f3 lit, albedo;
+    float roughness;
     f3 c;
     float w;
 };
+
+// global_light (:557) of a bounce whose coin chose sampleLight: spec_light is zero, so the second term
+// (specular * 0) * w is a zero of either sign for finite inputs and is left out.
+RT_DEV f3 diffuse_global_light(f3 albedo, float roughness, f3 diff_light) {
+    return ((albedo * diff_light) * roughness) * 2.0f;
+}
+// ... and of a bounce whose coin chose sampleLightGlossy (the term (albedo * 0) * roughness left out).
+RT_DEV f3 glossy_global_light(f3 specular, float w, f3 spec_light) {
+    return ((specular * spec_light) * w) * 2.0f;
+}
 
 // sampleLight up to its occlusion loop, raytracer.glsl:326-370 and :379-386.  Returns true when
 // the loop has to run; `lit` then holds the light the call returns if nothing occludes.
@@ -385,7 +425,7 @@ RT_DEV bool sample_light_setup(const DScene &sc, f3 position, f3 normal, uint32_
     float cx = unit_float(seed);
     float cy = unit_float(seed);
     if (cx + cy > 1.0f) { cx = 1.0f - cx; cy = 1.0f - cy; }
-    const f3 rand_tri = (lt.u * cx + lt.v * cy) + lt.p * 1.0f;
+    const f3 rand_tri = (lt.u * cx + lt.p) + lt.v * cy;     // UVP * vec3(coords, 1); Mesa: the constant-1 column is added second
     const f3 delta = rand_tri - position;
     max_t = length(delta);
     probe_d = mk3(delta.x / max_t, delta.y / max_t, delta.z / max_t);
@@ -395,7 +435,7 @@ RT_DEV bool sample_light_setup(const DScene &sc, f3 position, f3 normal, uint32_
     const ShadeRec ls = load_shade(sc, light_id);               // :379
     const Mat lm = load_mat(sc, ls.mat);
     const float tri_area = 0.5f * length(cross(lt.u, lt.v));
-    const float distance_ratio = __builtin_fmaf(max_t, max_t + 2.0f, 1.0f);
+    const float distance_ratio = max_t * (max_t + 2.0f) + 1.0f;      // fma() of :385; Mesa: separate multiply and add
     const float k = tri_area * (-DdL) * DdN / distance_ratio * (float)sc.lights;
     lit = lm.emission * k;
     return true;
@@ -447,14 +487,15 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
 
     const float cos_theta = gmax(-dot(normal, ps.d), 0.0f);
     const float transmission = (ior == 0.0f) ? 0.0f : get_transmission(cos_theta, 1.00029f, ior);
-    const float fresnel = __builtin_fmaf(1.0f - transmission, pow5(1.0f - cos_theta), transmission);
+    // fma() of :497; Mesa: separate multiply and add
+    const float fresnel = (1.0f - transmission) * gm::pow(1.0f - cos_theta, 5.0f) + transmission;
 
     const float rand_reflectance = unit_float(ps.seed);
     const float rand_scatter = unit_float(ps.seed);
     const float rand_metallic = unit_float(ps.seed);
 
-    const f3 old_o = ps.o;
-    ps.o = ps.o + ps.d * ht;                                                               // :507
+    const f3 travelled = ps.d * ht;
+    ps.o = ps.o + travelled;                                                               // :507
 
     const bool is_mirror = rand_reflectance < fresnel;                                     // :509
     const bool is_metal = !is_mirror && (rand_metallic < metallic);                        // :516
@@ -469,7 +510,7 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
         const f3 base = is_metal ? specular_ray : normal;
         const float sinx = __builtin_sqrtf(1.0f - x * x);
         float sn, cs;
-        dm::sincos(th, sn, cs);
+        gm::sincos(th, sn, cs);
         new_d = normalize(mk3(sinx * cs, sinx * sn, x) * scale + base);                    // :490-492
     }
     if (is_mirror) {                                                                       // :509-514
@@ -478,14 +519,14 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
     } else if (is_metal) {                                                                 // :516-522
         ps.path = ps.path * albedo;
     } else if (is_diffuse) {                                                               // :524-538
-        const float theta_i = dm::acos(cos_theta);
-        const float theta_o = dm::acos(dot(new_d, normal));
+        const float theta_i = gm::acos(cos_theta);
+        const float theta_o = gm::acos(dot(new_d, normal));
         const float var2 = roughness * roughness;
         const float A = 1.0f - 0.5f * var2 / (var2 + 0.33f);
         const float B = 0.45f * var2 / (var2 + 0.09f);
         const float alpha = gmax(theta_i, theta_o);
         const float beta = gmin(theta_i, theta_o);
-        const float w = (A + B * gmax(0.0f, theta_i - theta_o) * dm::sin(alpha) * dm::tan(beta)) * INV_PI_F * occlusion;
+        const float w = (A + B * gmax(0.0f, theta_i - theta_o) * gm::sin(alpha) * gm::tan(beta)) * INV_PI_F * occlusion;
         ps.path = ps.path * (albedo * w);
     } else {                                                                               // :539-545
         ps.path = ps.path * (specular * (1.0f - roughness));
@@ -498,22 +539,18 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
     bn.w = 0.0f;
     bn.max_t = 0.0f;
     bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
+    bn.lit = mk3(0.0f, 0.0f, 0.0f);
+    bn.albedo = albedo;
+    bn.roughness = roughness;
     if (coin_diffuse) {                                                                    // :553-554
-        f3 lit;
-        if (sample_light_setup(sc, ps.o, normal, ps.seed, bn.probe_d, bn.max_t, lit)) {
-            bn.kind = PROBE_SHADOW;
-            // global_light with spec_light = 0, raytracer.glsl:557
-            const float sw = fresnel + 1.0f - roughness;
-            bn.c = ((albedo * lit) * roughness + (specular * mk3(0.0f, 0.0f, 0.0f)) * sw) * 2.0f;
-        }
+        if (sample_light_setup(sc, ps.o, normal, ps.seed, bn.probe_d, bn.max_t, bn.lit)) bn.kind = PROBE_SHADOW;
     } else {                                                                               // :555-556, :398-401
-        const f3 viewDir = normalize(ps.o - old_o);
+        // position - view.position; Mesa: simplified to direction * t, the vector that was just added
+        const f3 viewDir = normalize(travelled);
         bn.probe_d = reflect(viewDir, normalize(random_sphere(ps.seed) * roughness + normal));
         bn.kind = PROBE_GLOSSY;
         bn.c = specular;
         bn.w = fresnel + 1.0f - roughness;
-        // albedo * diff_light * roughness with diff_light = 0 contributes (albedo*0)*roughness;
-        // that term is +-0 for finite inputs and is dropped in shade_post.
     }
 }
 
@@ -540,9 +577,19 @@ RT_DEV bool shade_post(const DScene &sc, PathState &ps, int current, bool has_li
     return true;
 }
 
-// global_light of a glossy probe that returned `spec_light`, raytracer.glsl:557 with diff_light = 0.
-RT_DEV f3 glossy_global_light(const Bounce &bn, f3 spec_light) {
-    return ((bn.c * spec_light) * bn.w) * 2.0f;
+// Rest of a bounce whose coin chose sampleLight.  `written`: the call returned true (the probe ran and
+// nothing occluded), so its result replaces the kept one.
+RT_DEV bool finish_diffuse(const DScene &sc, PathState &ps, int current, bool written, f3 lit, f3 albedo,
+                           float roughness) {
+    if (written) ps.kept_diff = lit;
+    return shade_post(sc, ps, current, written, diffuse_global_light(albedo, roughness, ps.kept_diff));
+}
+// Rest of a bounce whose coin chose sampleLightGlossy.  outcome 0: a non-emissive triangle was hit (nothing
+// written, false), 1: nothing was hit (sky), 2: the closest hit is the emissive triangle light_id.
+RT_DEV bool finish_glossy(const DScene &sc, const DFrame &fr, PathState &ps, int current, int outcome, f3 probe_d,
+                          int light_id, f4 lsec, f3 specular, float w) {
+    if (outcome != 0) ps.kept_spec = glossy_light(sc, fr, probe_d, outcome == 2 ? light_id : -1, lsec);
+    return shade_post(sc, ps, current, outcome != 0, glossy_global_light(specular, w, ps.kept_spec));
 }
 
 }  // namespace rt

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 
         ps.o = cam.o; ps.d = cam.d;
         ps.path = mk3(1.0f, 1.0f, 1.0f);
         ps.energy = mk3(0.0f, 0.0f, 0.0f);
+        ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
         bool alive = in_image;
         n_paths += alive ? 1u : 0u;
 
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 
             n_rays += alive ? 1u : 0u;
 
             Bounce bn;
-            bn.kind = PROBE_NONE; bn.current = 0; bn.max_t = 0.0f; bn.w = 0.0f;
-            bn.c = mk3(0.0f, 0.0f, 0.0f); bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
+            bn.kind = PROBE_NONE; bn.current = 0; bn.max_t = 0.0f; bn.w = 0.0f; bn.roughness = 0.0f;
+            bn.c = bn.lit = bn.albedo = bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
             bool shaded = false;
             if (alive) {
                 if (hit < 0) {
@@ -171,28 +172,26 @@ __global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 
                 }
             }
             Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
-            bool has_light = false;
-            f3 global_light = mk3(0.0f, 0.0f, 0.0f);
             if (coin_diffuse) {
                 const bool run = shaded && bn.kind == PROBE_SHADOW;
+                bool blocked = true;
                 if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                    const bool blocked = shadow_any_hit_bf(sc, probe, bn.max_t, bn.current, run);
+                    blocked = shadow_any_hit_bf(sc, probe, bn.max_t, bn.current, run);
                     n_shadow += run ? 1u : 0u;
-                    if (run && !blocked) { has_light = true; global_light = bn.c; }
                 }
+                if (shaded) alive = finish_diffuse(sc, ps, bn.current, run && !blocked, bn.lit, bn.albedo, bn.roughness);
             } else {
                 const bool run = shaded && bn.kind == PROBE_GLOSSY;
+                int outcome = 0, light_id = -1;
+                f4 lsec;
+                lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
                 if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                    int light_id; f4 lsec;
-                    const int outcome = glossy_search_bf(sc, probe, bn.current, run, light_id, lsec);
+                    outcome = glossy_search_bf(sc, probe, bn.current, run, light_id, lsec);
                     n_glossy += run ? 1u : 0u;
-                    if (run && outcome != 0) {
-                        has_light = true;
-                        global_light = glossy_global_light(bn, glossy_light(sc, fr, bn.probe_d, outcome == 2 ? light_id : -1, lsec));
-                    }
                 }
+                if (shaded)
+                    alive = finish_glossy(sc, fr, ps, bn.current, run ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
             }
-            if (shaded) alive = shade_post(sc, ps, bn.current, has_light, global_light);
         }
         acc = acc + ps.energy;
     }

@@ -19,8 +19,11 @@
 //
 // Path state lives in HBM as structure-of-arrays float4 planes indexed by path id:
 //   s0 = (o.xyz, d.x)  s1 = (d.yz, path.xy)  s2 = (path.z, energy.xyz)
-//   s3 = (seed, current triangle)            written by extend, read by the probe stages
-//   p0 = (probe_d.xyz, max_t)  p1 = (c.xyz, w)   (see struct Bounce)
+//   s3 = (seed, current triangle | kept flags << 30)
+//   p0 = (probe_d.xyz, max_t)
+//   p1 = (lit.xyz, roughness), p2 = (albedo.xyz, -) for shadow probes; p1 = (specular.xyz, w) for glossy probes
+//   kd = kept_diff.xyz, ks = kept_spec.xyz   (see struct PathState); read only when the matching flag
+//        in s3 says they were ever written, so the planes need no clearing between batches
 //   h0 = (u, v, t, hit triangle id)          written by extend, read by shade
 // Path id = slot * paths_per_sample + tile * 64 + lane, where `slot` is the sample's position in
 // the batch and (tile, lane) is the 8x8 pixel tile and the pixel inside it, so that the depth-0
@@ -44,7 +47,7 @@ constexpr int PIPE_WAVES = 256 * 16;    // persistent grid: 16 single-wave workg
 // entries always suffices.  With one atomic per wave and queue on three shared counters the shade
 // stage spent 87 % of its time waiting (2.2 ms for 8.3 M paths); the regions took that away.
 struct PipeBuffers {
-    float4 *s0, *s1, *s2, *p0, *p1, *h0;
+    float4 *s0, *s1, *s2, *p0, *p1, *p2, *kd, *ks, *h0;
     uint2 *s3;
     uint32_t *q_ext[2], *q_shadow, *q_glossy;   // PIPE_WAVES regions of region_cap path ids each
     uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
@@ -63,6 +66,9 @@ RT_DEV void load_path(const PipeBuffers &b, uint32_t id, PathState &ps) {
     ps.path = mk3(c.z, c.w, e.x);
     ps.energy = mk3(e.y, e.z, e.w);
 }
+constexpr uint32_t KEPT_DIFF = 1u, KEPT_SPEC = 2u;      // flag bits kept in s3.y >> 30
+constexpr uint32_t CURRENT_MASK = 0x3FFFFFFFu;
+
 RT_DEV void store_path(const PipeBuffers &b, uint32_t id, const PathState &ps) {
     b.s0[id] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
     b.s1[id] = make_float4(ps.d.y, ps.d.z, ps.path.x, ps.path.y);
@@ -88,7 +94,8 @@ struct RouteFill { uint32_t shadow, glossy, next; };
 // probe needed) through shade_post to the next extend queue.  Called by whole waves; `live` masks lanes.
 RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffers &b, int depth, int q_in,
                             const uint32_t *__restrict__ coins, uint32_t paths_per_sample, int max_depth, bool live,
-                            uint32_t id, PathState &ps, int hit, float hu, float hv, float ht, RouteFill &fill) {
+                            uint32_t id, PathState &ps, uint32_t kept_flags, int hit, float hu, float hv, float ht,
+                            RouteFill &fill) {
     bool to_shadow = false, to_glossy = false, to_next = false;
     if (live) {
         if (hit < 0) {
@@ -99,14 +106,22 @@ RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffer
             Bounce bn;
             shade_pre(sc, fr, ps, hit, hu, hv, ht, coin_diffuse, bn);
             if (bn.kind == PROBE_NONE) {
-                to_next = shade_post(sc, ps, hit, false, mk3(0.0f, 0.0f, 0.0f));
+                // sampleLight returned false before its occlusion loop: the kept light enters the roulette
+                ps.kept_diff = mk3(0.0f, 0.0f, 0.0f);
+                if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
+                to_next = finish_diffuse(sc, ps, hit, false, bn.lit, bn.albedo, bn.roughness);
             } else {
                 b.p0[id] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
-                b.p1[id] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
+                if (bn.kind == PROBE_SHADOW) {
+                    b.p1[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, bn.roughness);
+                    b.p2[id] = make_float4(bn.albedo.x, bn.albedo.y, bn.albedo.z, 0.0f);
+                } else {
+                    b.p1[id] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
+                }
                 to_shadow = bn.kind == PROBE_SHADOW;
                 to_glossy = bn.kind == PROBE_GLOSSY;
             }
-            b.s3[id] = make_uint2(ps.seed, (uint32_t)hit);
+            b.s3[id] = make_uint2(ps.seed, (uint32_t)hit | (kept_flags << 30));
         }
         store_path(b, id, ps);
     }
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, Pi
     for (uint32_t base = FIRST ? blockIdx.x * 64u : 0u; base < total; base += FIRST ? gridDim.x * 64u : 64u) {
         const uint32_t qi = base + lane;
         bool live = qi < total;
-        uint32_t id = 0;
+        uint32_t id = 0, kept_flags = 0;
         PathState ps;
         if (FIRST) {
             id = qi;
@@ -172,7 +187,9 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, Pi
             id = live ? q[qi] : 0u;
             if (FUSED) {
                 load_path(b, id, ps);
-                ps.seed = b.s3[id].x;
+                const uint2 s3v = b.s3[id];
+                ps.seed = s3v.x;
+                kept_flags = s3v.y >> 30;
             } else {
                 const float4 a = b.s0[id], c = b.s1[id];
                 ps.o = mk3(a.x, a.y, a.z);
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, Pi
                             : closest_hit_bf(sc, ray, isec);
         const float inv_det = 1.0f / isec.w;
         if (FUSED) {
-            shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, hit,
+            shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, kept_flags, hit,
                             isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, fill);
         } else if (live) {
             b.h0[id] = make_float4(isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, __int_as_float(hit));
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(64) void k_shade(DScene sc, DFrame fr, PipeBuffers 
     for (uint32_t base = FIRST ? blockIdx.x * 64u : 0u; base < total; base += FIRST ? gridDim.x * 64u : 64u) {
         const uint32_t qi = base + lane;
         bool live = qi < total;
-        uint32_t id = 0;
+        uint32_t id = 0, kept_flags = 0;
         PathState ps;
         if (FIRST) {
             // the camera ray is cheap to regenerate (raytracer.glsl:594-606): no state was stored for depth 0
@@ -235,11 +252,13 @@ __global__ __launch_bounds__(64) void k_shade(DScene sc, DFrame fr, PipeBuffers 
         } else {
             id = live ? q[qi] : 0u;
             load_path(b, id, ps);
-            ps.seed = b.s3[id].x;
+            const uint2 s3v = b.s3[id];
+            ps.seed = s3v.x;
+            kept_flags = s3v.y >> 30;
         }
         const float4 h = b.h0[id];
-        shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, __float_as_int(h.w),
-                        h.x, h.y, h.z, fill);
+        shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, kept_flags,
+                        __float_as_int(h.w), h.x, h.y, h.z, fill);
     }
     store_route_fill(b, q_in, fill);
 }
@@ -264,19 +283,26 @@ __global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuf
         Ray probe;
         probe.o = mk3(a.x, a.y, a.z);
         probe.d = mk3(pr.x, pr.y, pr.z);
-        const bool blocked = BVH ? shadow_any_hit_bvh(sc, bv, probe, pr.w, (int)sc3.y, live, stack, bc)
-                                 : shadow_any_hit_bf(sc, probe, pr.w, (int)sc3.y, live);
+        const int current = (int)(sc3.y & CURRENT_MASK);
+        uint32_t kept_flags = sc3.y >> 30;
+        const bool blocked = BVH ? shadow_any_hit_bvh(sc, bv, probe, pr.w, current, live, stack, bc)
+                                 : shadow_any_hit_bf(sc, probe, pr.w, current, live);
         bool to_next = false;
         if (live) {
             PathState ps;
             load_path(b, id, ps);
             ps.seed = sc3.x;
-            const float4 c = b.p1[id];
-            const bool has_light = !blocked;
-            const f3 gl = has_light ? mk3(c.x, c.y, c.z) : mk3(0.0f, 0.0f, 0.0f);
-            to_next = shade_post(sc, ps, (int)sc3.y, has_light, gl);
+            const float4 c = b.p1[id], al = b.p2[id];
+            ps.kept_diff = mk3(0.0f, 0.0f, 0.0f);
+            if (blocked) {
+                if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
+            } else {
+                b.kd[id] = make_float4(c.x, c.y, c.z, 0.0f);
+                kept_flags |= KEPT_DIFF;
+            }
+            to_next = finish_diffuse(sc, ps, current, !blocked, mk3(c.x, c.y, c.z), mk3(al.x, al.y, al.z), c.w);
             store_path(b, id, ps);
-            b.s3[id] = make_uint2(ps.seed, sc3.y);
+            b.s3[id] = make_uint2(ps.seed, (uint32_t)current | (kept_flags << 30));
         }
         to_next = to_next && (depth + 1 < max_depth);
         region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next, id);
@@ -312,23 +338,25 @@ __global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DBvh bv, DBvh lb
         probe.d = mk3(pr.x, pr.y, pr.z);
         int light_id;
         f4 lsec;
-        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, probe, (int)sc3.y, live, light_id, lsec, stack, bc)
-                                : glossy_search_bf(sc, probe, (int)sc3.y, live, light_id, lsec);
+        const int current = (int)(sc3.y & CURRENT_MASK);
+        uint32_t kept_flags = sc3.y >> 30;
+        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, probe, current, live, light_id, lsec, stack, bc)
+                                : glossy_search_bf(sc, probe, current, live, light_id, lsec);
         bool to_next = false;
         if (live) {
             PathState ps;
             load_path(b, id, ps);
             ps.seed = sc3.x;
             const float4 c = b.p1[id];
-            Bounce bn;
-            bn.c = mk3(c.x, c.y, c.z);
-            bn.w = c.w;
-            const bool has_light = outcome != 0;
-            f3 gl = mk3(0.0f, 0.0f, 0.0f);
-            if (has_light) gl = glossy_global_light(bn, glossy_light(sc, fr, probe.d, outcome == 2 ? light_id : -1, lsec));
-            to_next = shade_post(sc, ps, (int)sc3.y, has_light, gl);
+            ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
+            if (outcome == 0 && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
+            to_next = finish_glossy(sc, fr, ps, current, outcome, probe.d, light_id, lsec, mk3(c.x, c.y, c.z), c.w);
+            if (outcome != 0) {
+                b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
+                kept_flags |= KEPT_SPEC;
+            }
             store_path(b, id, ps);
-            b.s3[id] = make_uint2(ps.seed, sc3.y);
+            b.s3[id] = make_uint2(ps.seed, (uint32_t)current | (kept_flags << 30));
         }
         to_next = to_next && (depth + 1 < max_depth);
         region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next, id);
@@ -385,9 +413,10 @@ struct Pipeline {
 
     void free_paths() {
         (void)hipFree(buf.s0); (void)hipFree(buf.s1); (void)hipFree(buf.s2); (void)hipFree(buf.s3);
-        (void)hipFree(buf.p0); (void)hipFree(buf.p1); (void)hipFree(buf.h0);
+        (void)hipFree(buf.p0); (void)hipFree(buf.p1); (void)hipFree(buf.p2); (void)hipFree(buf.kd); (void)hipFree(buf.ks);
+        (void)hipFree(buf.h0);
         (void)hipFree(buf.q_ext[0]); (void)hipFree(buf.q_ext[1]); (void)hipFree(buf.q_shadow); (void)hipFree(buf.q_glossy);
-        buf.s0 = buf.s1 = buf.s2 = buf.p0 = buf.p1 = buf.h0 = nullptr;
+        buf.s0 = buf.s1 = buf.s2 = buf.p0 = buf.p1 = buf.p2 = buf.kd = buf.ks = buf.h0 = nullptr;
         buf.s3 = nullptr;
         buf.q_ext[0] = buf.q_ext[1] = buf.q_shadow = buf.q_glossy = nullptr;
         cap_paths = 0;
@@ -435,6 +464,9 @@ struct Pipeline {
             PIPE_ALLOC(buf.s3, sizeof(uint2) * paths);
             PIPE_ALLOC(buf.p0, sizeof(float4) * paths);
             PIPE_ALLOC(buf.p1, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.p2, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.kd, sizeof(float4) * paths);
+            PIPE_ALLOC(buf.ks, sizeof(float4) * paths);
             PIPE_ALLOC(buf.h0, sizeof(float4) * paths);
             PIPE_ALLOC(buf.q_ext[0], sizeof(uint32_t) * qn);
             PIPE_ALLOC(buf.q_ext[1], sizeof(uint32_t) * qn);

@@ -38,6 +38,8 @@ def _load(libm):
     lib.orc_unpack_r11g11b10.argtypes = [c.c_uint32, fp]
     lib.orc_math.restype = c.c_float
     lib.orc_math.argtypes = [c.c_int, c.c_float, c.c_float]
+    lib.orc_math_batch.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_uint64, c.c_void_p]
+    lib.orc_sample_env.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_void_p]
     lib.orc_scene_create.restype = c.c_void_p
     lib.orc_scene_create.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint32, c.c_void_p, c.c_uint32]
     lib.orc_scene_destroy.argtypes = [c.c_void_p]
@@ -81,9 +83,20 @@ def random_sphere(seed, libm=False):
     return np.array(out[:], dtype=np.float32), int(s.value)
 
 
+_MATH_CODES = {"sin": 0, "cos": 1, "tan": 2, "acos": 3, "asin": 4, "atan2": 5, "pow5": 6}
+
+
 def math_fn(which, x, y=0.0, libm=False):
-    names = {"sin": 0, "cos": 1, "tan": 2, "acos": 3, "asin": 4, "atan2": 5, "pow5": 6}
-    return np.float32(_load(libm).orc_math(names[which], ctypes.c_float(x), ctypes.c_float(y)))
+    return np.float32(_load(libm).orc_math(_MATH_CODES[which], ctypes.c_float(x), ctypes.c_float(y)))
+
+
+def math_batch(which, x, y=None, libm=False):
+    """Vector form of math_fn: float32 arrays in, float32 array out."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    yy = None if y is None else np.ascontiguousarray(np.broadcast_to(np.asarray(y, dtype=np.float32), x.shape))
+    out = np.empty_like(x)
+    _load(libm).orc_math_batch(_MATH_CODES[which], _ptr(x), None if yy is None else _ptr(yy), x.size, _ptr(out))
+    return out
 
 
 def pack_r11g11b10(r, g, b):
@@ -143,6 +156,13 @@ class OracleScene:
         rgba = np.ascontiguousarray(rgba, dtype=np.float32)
         h, w = rgba.shape[:2]
         self.lib.orc_scene_upload_env(self.h, w, h, _ptr(rgba))
+
+    def sample_env(self, st):
+        """Bilinear environment lookups: st[n, 2] -> rgb[n, 3]."""
+        st = np.ascontiguousarray(st, dtype=np.float32)
+        rgb = np.empty((len(st), 3), dtype=np.float32)
+        self.lib.orc_sample_env(self.h, _ptr(st), len(st), _ptr(rgb))
+        return rgb
 
     def closest_hit_batch(self, o, d):
         o = np.ascontiguousarray(o, dtype=np.float32)

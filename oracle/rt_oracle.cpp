@@ -6,28 +6,33 @@
 //
 // It follows res/shader/raytracer.glsl of the reference function by function (each
 // function below cites the lines it restates) in IEEE float32, with no floating-point
-// contraction (build with -ffp-contract=off) and with the association order of dot()
-// fixed by ORC_DOT_ORDER.
+// contraction (build with -ffp-contract=off).
 //
-// PARITY UNPINNED: the reference ships no tests, golden images or known-answer
-// vectors for this path, and its shader cannot be executed in the build container,
-// so the only pins are the PCG hash values worked out by hand from raytracer.glsl:83-98.
-// Precision of the GLSL built-ins (sin, cos, acos, asin, atan, tan, pow, normalize,
-// texture filtering) is left to the GL driver by the GLSL specification; this
-// restatement fixes them as documented next to each helper.
+// PINNED AGAINST THE REFERENCE: the reference ships no tests or golden images for this path,
+// but its unmodified shader runs in the build container under Mesa 23.2 llvmpipe
+// (oracle/glsl_ref/run_reference_glsl.c).  Where GLSL leaves the arithmetic to the GL
+// implementation (association order of dot() and of matrix products, fused or separate
+// multiply-add, x/y or x*(1/y), the elementary functions) this restatement follows what Mesa
+// generates for this shader, so that hit ids, (u, v, t) and whole images can be compared with
+// the llvmpipe run; tests/golden/ holds those outputs and tests/test_reference_glsl.py checks them.
+// Each such choice is marked "Mesa:" below.
 //
 // Two math back ends, chosen at compile time:
 //   ORC_LIBM = 1  elementary functions from the C library (independent of the product)
-//   ORC_LIBM = 0  the deterministic functions of rt_detmath.h, the same header the device
-//                 code uses, so that whole images can be compared bit for bit
+//   ORC_LIBM = 0  the functions of rt_glslmath.h (bit-identical to llvmpipe's), the same header
+//                 the device code uses, so that whole images can be compared bit for bit
 //
 // Places where the shader's behaviour is undefined and this restatement defines it:
 //   * sampleLight reads triangleModels[light_id - 1] with light_id possibly 0, and
 //     triangleShadings[light_id] with light_id possibly LIGHTS == COUNT
 //     (raytracer.glsl:336-338, :379): out-of-range reads return an all-zero record.
 //   * `out vec3 light` left unwritten on a false return (:333-334, :369-370, :376-377,
-//     :420-425): treated as zero (the caller initialises it to zero at :549-550 anyway).
-//   * asin / acos arguments outside [-1, 1] (:274, :527-528) are clamped.
+//     :420-425).  The value still reaches global_light and through it the Russian-roulette
+//     brightness (:557, :575).  Mesa: after inlining, each of the two functions keeps one `light`
+//     variable for the whole pixel-sample, so an unwritten result is the value that function wrote
+//     last at an earlier depth (zero before its first write); this restatement does the same.
+//   * asin / acos arguments outside [-1, 1] (:274, :527-528): NaN with rt_glslmath.h (as Mesa), clamped
+//     with the C library back end; a non-finite texture coordinate samples texel (0, 0).
 
 #include <cmath>
 #include <cstdint>
@@ -40,11 +45,11 @@
 #define ORC_LIBM 0
 #endif
 #ifndef ORC_DOT_ORDER
-#define ORC_DOT_ORDER 0   // 0: (x*x' + y*y') + z*z'    1: (z*z' + y*y') + x*x'
+#define ORC_DOT_ORDER 1   // 0: (x*x' + y*y') + z*z'    1: (z*z' + y*y') + x*x'  (Mesa: the last component first)
 #endif
 
 #if !ORC_LIBM
-#include "../gpuraytracer_amd/csrc/rt_detmath.h"
+#include "../gpuraytracer_amd/csrc/rt_glslmath.h"
 #endif
 
 namespace {
@@ -100,9 +105,9 @@ inline V3 reflect(V3 I, V3 N) {
     const float k = 2.0f * dot(N, I);
     return I - N * k;
 }
-// GLSL max/min/clamp exactly as specified: max(x,y) = (x < y) ? y : x, min(x,y) = (y < x) ? y : x
-inline float gmax(float x, float y) { return (x < y) ? y : x; }
-inline float gmin(float x, float y) { return (y < x) ? y : x; }
+// Mesa: max/min are IEEE maxNum/minNum (a NaN operand yields the other operand)
+inline float gmax(float x, float y) { return fmaxf(x, y); }
+inline float gmin(float x, float y) { return fminf(x, y); }
 inline float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 
 // Elementary functions.
@@ -115,13 +120,13 @@ inline float m_asin(float x) { return asinf(gclamp(x, -1.0f, 1.0f)); }
 inline float m_atan2(float y, float x) { return atan2f(y, x); }
 inline float m_pow5(float x) { return powf(x, 5.0f); }
 #else
-inline void m_sincos(float x, float &s, float &c) { dm::sincos(x, s, c); }
-inline float m_sin(float x) { return dm::sin(x); }
-inline float m_tan(float x) { return dm::tan(x); }
-inline float m_acos(float x) { return dm::acos(x); }
-inline float m_asin(float x) { return dm::asin(x); }
-inline float m_atan2(float y, float x) { return dm::atan2(y, x); }
-inline float m_pow5(float x) { const float x2 = x * x; return (x2 * x2) * x; }
+inline void m_sincos(float x, float &s, float &c) { gm::sincos(x, s, c); }
+inline float m_sin(float x) { return gm::sin(x); }
+inline float m_tan(float x) { return gm::tan(x); }
+inline float m_acos(float x) { return gm::acos(x); }
+inline float m_asin(float x) { return gm::asin(x); }
+inline float m_atan2(float y, float x) { return gm::atan2(y, x); }
+inline float m_pow5(float x) { return gm::pow(x, 5.0f); }
 #endif
 
 const float PI = 3.141592653589793f;
@@ -160,6 +165,12 @@ struct Stats {
 };
 
 struct Ray { V3 position, direction; };
+
+// ORC_DEBUG=1 in the environment prints one line per bounce to stderr
+inline bool orc_debug() {
+    static const bool on = getenv("ORC_DEBUG") != nullptr;
+    return on;
+}
 
 const TriModel ZERO_MODEL = {};
 const TriShading ZERO_SHADING = {};
@@ -257,7 +268,11 @@ inline float getTransmission(float cosThetaI, float etaI, float etaT) {
     const float cosThetaT = sqrtf(1.0f - sinThetaT * sinThetaT);
     const float r0 = (etaT * cosThetaI - etaI * cosThetaT) / (etaT * cosThetaI + etaI * cosThetaT);
     const float r1 = (etaI * cosThetaI - etaT * cosThetaT) / (etaI * cosThetaI + etaT * cosThetaT);
+#if ORC_DOT_ORDER == 0
     return (r0 * r0 + r1 * r1) * 0.5f;
+#else
+    return (r1 * r1 + r0 * r0) * 0.5f;
+#endif
 }
 
 // calculateN, raytracer.glsl:239-248: normalize(N * vec3(1-u-v, u, v)), mat3 * vec3 summed column by column
@@ -327,31 +342,42 @@ inline V3 unpack_r11g11b10(uint32_t p) {
     return V3{uf_decode(p & 0x7FFu, 6), uf_decode((p >> 11) & 0x7FFu, 6), uf_decode(p >> 22, 5)};
 }
 
-// Bilinear filtering with REPEAT wrapping, fixed as
-//   x = s*W - 0.5, i0 = floor(x), a = x - i0;  texel = (t00*(1-a) + t10*a)*(1-b) + (t01*(1-a) + t11*a)*b
-// Non-finite or huge coordinates sample texel (0, 0).
+// Bilinear filtering with REPEAT wrapping.  Mesa (llvmpipe), per axis of length L:
+//   L a power of two:  x = c*L - 0.5;  i = floor(x);  texels i & (L-1), (i+1) & (L-1)
+//   otherwise:         c = c - floor(c);  x = c*L - 0.5;  i = floor(x);  texels (x < 0 ? L-1 : i), (i+1 == L ? 0 : i+1)
+//   weight w = x - floor(x);  lerp(w, v0, v1) = fma(w, v1 - v0, v0), first along s for both rows, then along t.
+// A coordinate whose texel index does not fit an int (NaN included) uses index 0; its weight follows from
+// the same arithmetic (NaN for NaN and infinities, which makes the sample NaN).
 struct Bilinear { int i0, i1, j0, j1; float a, b; };
+inline void wrap_repeat_linear(float c, uint32_t L, int &i0, int &i1, float &w) {
+    const int n = (int)L;
+    const bool pot = (L & (L - 1u)) == 0u;
+    if (!pot) c = c - floorf(c);
+    const float x = c * (float)L - 0.5f;
+    const float fl = floorf(x);
+    w = x - fl;
+    const bool in_range = fabsf(fl) < 2147483648.0f;
+    const int i = in_range ? (int)fl : 0;
+    if (pot) {
+        i0 = i & (n - 1);
+        i1 = (i + 1) & (n - 1);
+    } else {
+        i0 = (x < 0.0f) ? n - 1 : i;
+        i1 = (i + 1 >= n) ? 0 : i + 1;
+        if (!in_range || i0 >= n) { i0 = 0; i1 = 0; }
+    }
+}
 inline Bilinear bilinear_setup(float s, float t, uint32_t W, uint32_t H) {
-    float x = s * (float)W - 0.5f, y = t * (float)H - 0.5f;
-    if (!(fabsf(x) < 1073741824.0f)) x = 0.0f;
-    if (!(fabsf(y) < 1073741824.0f)) y = 0.0f;
-    const float fx = floorf(x), fy = floorf(y);
     Bilinear bl;
-    bl.a = x - fx;
-    bl.b = y - fy;
-    const int ix = (int)fx, iy = (int)fy;
-    const int w = (int)W, h = (int)H;
-    bl.i0 = ((ix % w) + w) % w;
-    bl.i1 = (((ix + 1) % w) + w) % w;
-    bl.j0 = ((iy % h) + h) % h;
-    bl.j1 = (((iy + 1) % h) + h) % h;
+    wrap_repeat_linear(s, W, bl.i0, bl.i1, bl.a);
+    wrap_repeat_linear(t, H, bl.j0, bl.j1, bl.b);
     return bl;
 }
+inline float lerp1(float w, float v0, float v1) { return fmaf(w, v1 - v0, v0); }
 inline V3 bilinear_mix(V3 t00, V3 t10, V3 t01, V3 t11, float a, float b) {
-    const float ia = 1.0f - a, ib = 1.0f - b;
-    const V3 top = t00 * ia + t10 * a;
-    const V3 bot = t01 * ia + t11 * a;
-    return top * ib + bot * b;
+    const V3 top = V3{lerp1(a, t00.x, t10.x), lerp1(a, t00.y, t10.y), lerp1(a, t00.z, t10.z)};
+    const V3 bot = V3{lerp1(a, t01.x, t11.x), lerp1(a, t01.y, t11.y), lerp1(a, t01.z, t11.z)};
+    return V3{lerp1(b, top.x, bot.x), lerp1(b, top.y, bot.y), lerp1(b, top.z, bot.z)};
 }
 
 inline V3 sampleEnv(const Scene &sc, float s, float t) {
@@ -394,7 +420,7 @@ inline bool sampleLight(const Scene &sc, V3 position, V3 normal, int current, ui
     float cy = unitFloat(seed);
     if (cx + cy > 1.0f) { cx = 1.0f - cx; cy = 1.0f - cy; }
 
-    const V3 rand_tri = (U * cx + V * cy) + P * 1.0f;               // UVP * vec3(coords, 1.0)
+    const V3 rand_tri = (U * cx + P) + V * cy;     // UVP * vec3(coords, 1.0); Mesa: the constant-1 column is added second
     const V3 delta = rand_tri - position;
     const float max_t = length(delta);
 
@@ -418,16 +444,18 @@ inline bool sampleLight(const Scene &sc, V3 position, V3 normal, int current, ui
     const float tri_area = 0.5f * length(cross(U, V));
     const float light_vis_area_ratio = -DdL;
     const float probe_ratio = DdN;
-    const float distance_ratio = fmaf(max_t, max_t + 2.0f, 1.0f);
+    const float distance_ratio = max_t * (max_t + 2.0f) + 1.0f;     // fma() of :385; Mesa: separate multiply and add
     const float k = tri_area * light_vis_area_ratio * probe_ratio / distance_ratio * (float)LIGHTS;
     light = v3(material.emission_ior) * k;
     return true;
 }
 
 // sampleLightGlossy, raytracer.glsl:391-438
-inline bool sampleLightGlossy(const Scene &sc, const Frame &fr, V3 position, V3 normal, const Ray &view,
+// `view_delta` is position - view.position.  Mesa: position is view.position + direction * t, and the compiler
+// simplifies the difference to direction * t, so that is what the caller passes.
+inline bool sampleLightGlossy(const Scene &sc, const Frame &fr, V3 position, V3 normal, V3 view_delta,
                               float roughness, int current, uint32_t &seed, V3 &light, Stats &st) {
-    const V3 viewDir = normalize(position - view.position);
+    const V3 viewDir = normalize(view_delta);
     Ray probe;
     probe.position = position;
     probe.direction = reflect(viewDir, normalize(randomSphere(seed) * roughness + normal));
@@ -463,6 +491,8 @@ V3 trace(const Scene &sc, const Frame &fr, Ray ray, uint32_t seed, uint32_t ligh
     V3 path = V3{1, 1, 1};
     const int LIGHTS = (int)sc.lights;
     const int MAX_RECURSION = fr.recursion > 1 ? fr.recursion : 1;
+    // the `light` result variables of sampleLight / sampleLightGlossy, kept across depths (see the header)
+    V3 kept_diff_light = V3{0, 0, 0}, kept_spec_light = V3{0, 0, 0};
 
     for (int depth = 0; depth < MAX_RECURSION; depth++) {
         V3 sec;
@@ -509,7 +539,8 @@ V3 trace(const Scene &sc, const Frame &fr, Ray ray, uint32_t seed, uint32_t ligh
 
         const float cos_theta = gmax(-dot(normal, ray.direction), 0.0f);                    // :494
         const float transmission = (ior == 0.0f) ? 0.0f : getTransmission(cos_theta, 1.00029f, ior);
-        const float fresnel_reflectance = fmaf(1.0f - transmission, m_pow5(1.0f - cos_theta), transmission);
+        // fma() of :497; Mesa: separate multiply and add
+        const float fresnel_reflectance = (1.0f - transmission) * m_pow5(1.0f - cos_theta) + transmission;
 
         const float rand_reflectance = unitFloat(seed);
         const float rand_scatter = unitFloat(seed);
@@ -543,16 +574,19 @@ V3 trace(const Scene &sc, const Frame &fr, Ray ray, uint32_t seed, uint32_t ligh
 
         V3 diff_light = V3{0, 0, 0}, spec_light = V3{0, 0, 0};
         bool has_light;
-        if (unitFloat(light_seed) < 0.5f)                                                   // :553-556
-            has_light = sampleLight(sc, ray.position, normal, current_tri, seed, diff_light, st);
-        else
-            has_light = sampleLightGlossy(sc, fr, ray.position, normal, old_ray, roughness, current_tri, seed,
-                                          spec_light, st);
+        if (unitFloat(light_seed) < 0.5f) {                                                 // :553-556
+            has_light = sampleLight(sc, ray.position, normal, current_tri, seed, kept_diff_light, st);
+            diff_light = kept_diff_light;
+        } else {
+            has_light = sampleLightGlossy(sc, fr, ray.position, normal, old_ray.direction * sec.z, roughness,
+                                          current_tri, seed, kept_spec_light, st);
+            spec_light = kept_spec_light;
+        }
         const float sw = fresnel_reflectance + 1.0f - roughness;
         const V3 global_light = ((albedo * diff_light) * roughness + (specular * spec_light) * sw) * 2.0f;   // :557
 
         if (has_light) energy = energy + path * global_light;
-        if (getenv("ORC_DEBUG"))
+        if (orc_debug())
             fprintf(stderr, "depth %d tri %d mat %u sec %g %g %g N %g %g %g rough %g fres %g path %g %g %g dir %g %g %g "
                     "has_light %d gl %g %g %g energy %g %g %g\n", depth, current_tri, mat_id, sec.x, sec.y, sec.z,
                     normal.x, normal.y, normal.z, roughness, fresnel_reflectance, path.x, path.y, path.z,
@@ -560,10 +594,12 @@ V3 trace(const Scene &sc, const Frame &fr, Ray ray, uint32_t seed, uint32_t ligh
                     global_light.z, energy.x, energy.y, energy.z);
 
         const V3 true_normal = v3(sc.models[current_tri].n);                                // :568-571
+        if (orc_debug()) fprintf(stderr, "  term dot %.9g\n", dot(ray.direction, true_normal));
         if (dot(ray.direction, true_normal) <= 0.0f) break;
 
         const float brightness =
             gclamp(gmax(dot(global_light, path), (path.x + path.y + path.z) / 3.0f), 1.0f / 8.0f, 1.0f);   // :575
+        if (orc_debug()) { uint32_t s2 = seed; fprintf(stderr, "  roulette brightness %.9g rand %.9g\n", brightness, unitFloat(s2)); }
         if (unitFloat(seed) > brightness) break;
         path = V3{path.x / brightness, path.y / brightness, path.z / brightness};
     }
@@ -639,6 +675,19 @@ float orc_math(int which, float x, float y) {
         case 4: return m_asin(x);
         case 5: return m_atan2(x, y);
         default: return m_pow5(x);
+    }
+}
+
+void orc_math_batch(int which, const float *x, const float *y, uint64_t n, float *out) {
+    for (uint64_t i = 0; i < n; i++) out[i] = orc_math(which, x[i], y ? y[i] : 0.0f);
+}
+
+// Bilinear lookups in the environment map, (s, t) pairs in, rgb out.
+void orc_sample_env(const void *h, const float *st, uint64_t n, float *rgb) {
+    const Scene *sc = (const Scene *)h;
+    for (uint64_t i = 0; i < n; i++) {
+        const V3 c = sampleEnv(*sc, st[2 * i], st[2 * i + 1]);
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
     }
 }
 

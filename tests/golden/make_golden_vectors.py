@@ -1,11 +1,11 @@
-"""Writes the golden vectors under tests/golden/ with the CPU checker (oracle/, deterministic math
-back end):
-  rays_<scene>.npz   4096 rays (origins, directions) with closest-hit ids and (u, v, t)
+"""Writes golden vectors under tests/golden/ with the CPU checker (oracle/, the back end whose
+arithmetic equals llvmpipe's):
   image_cubes_<spp>spp.npz  64x64 per-pixel radiance SUMS of SAMPLE 0..spp-1, constant environment,
                      CLOCK 95834783, RECURSION 6, plus the ray/probe counters of that render
 Run in the build container:  python tests/golden/make_golden_vectors.py
-These pin this repository's own restatement (the reference has no fixtures for this path); a
-change of a vector means the arithmetic contract changed and has to be deliberate.
+These pin the accumulation (sums instead of the reference's running mean) and the work counters, which the
+reference does not output; the vectors made by the reference itself are written by
+make_glsl_reference_vectors.py, which also uses ray_batch() below.
 """
 import os
 import sys
@@ -59,13 +59,6 @@ def ray_batch(models, n=4096, seed=7):
 
 def main():
     oracle.build()
-    for name in ("cubes", "_ObiWan"):
-        models, shadings, lights, materials = load_scene(name)
-        sc = oracle.OracleScene(models, shadings, lights, materials)
-        o, d = ray_batch(models)
-        ids, uvt = sc.closest_hit_batch(o, d)
-        np.savez_compressed(os.path.join(HERE, "rays_%s.npz" % name), o=o, d=d, ids=ids, uvt=uvt)
-        print(name, "hits", int((ids >= 0).sum()), "of", len(ids))
     models, shadings, lights, materials = load_scene("cubes")
     sc = oracle.OracleScene(models, shadings, lights, materials)
     sc.upload_env(constant_env())

@@ -99,41 +99,39 @@ def test_r11g11b10_roundtrip(oracle_mod):
     assert oracle_mod.unpack_r11g11b10(oracle_mod.pack_r11g11b10(1.0 + 3.0 / 128, 0, 0))[0] == np.float32(1.0 + 2.0 / 64)
 
 
-def test_detmath_accuracy(oracle_mod):
-    # the deterministic functions stay within 2 ulp (tan, atan2: 4) of a float64 evaluation
+def test_builtins_are_sane(oracle_mod):
+    # the restated GL built-ins are approximations: polynomial sin/cos within 2 ulp, the asin/acos/atan
+    # approximations within 1e-3 rad, pow(x, 5) within 1e-4 relative
     rng = np.random.default_rng(3)
-
-    def ulp_err(got, want):
-        want32 = np.float32(want)
-        return abs(float(got) - want) / float(np.spacing(np.abs(want32)) if want32 != 0 else 1e-45)
-
-    worst = 0.0
-    for x in rng.uniform(0, 2 * np.pi, 2000).astype(np.float32):
-        worst = max(worst, ulp_err(oracle_mod.math_fn("sin", x), np.sin(np.float64(x))) if abs(np.sin(np.float64(x))) > 1e-3 else 0)
-        worst = max(worst, ulp_err(oracle_mod.math_fn("cos", x), np.cos(np.float64(x))) if abs(np.cos(np.float64(x))) > 1e-3 else 0)
-    for x in rng.uniform(-1, 1, 2000).astype(np.float32):
-        worst = max(worst, ulp_err(oracle_mod.math_fn("acos", x), np.arccos(np.float64(x))))
-        if abs(x) > 1e-3:
-            worst = max(worst, ulp_err(oracle_mod.math_fn("asin", x), np.arcsin(np.float64(x))))
-    for x in rng.uniform(0, 1.5, 1000).astype(np.float32):
-        worst = max(worst, ulp_err(oracle_mod.math_fn("tan", x), np.tan(np.float64(x))))
-    for y, x in rng.normal(size=(2000, 2)).astype(np.float32):
-        worst = max(worst, ulp_err(oracle_mod.math_fn("atan2", y, x), np.arctan2(np.float64(y), np.float64(x))))
-    assert worst <= 4.0, worst
-    assert oracle_mod.math_fn("acos", 1.0) == 0.0 and oracle_mod.math_fn("acos", 2.0) == 0.0
-    assert oracle_mod.math_fn("asin", -3.0) == np.float32(-np.pi / 2)
-    assert oracle_mod.math_fn("atan2", 0.0, 0.0) == 0.0
+    x = rng.uniform(0, 2 * np.pi, 4000).astype(np.float32)
+    assert np.abs(oracle_mod.math_batch("sin", x) - np.sin(x.astype(np.float64))).max() < 3e-7
+    assert np.abs(oracle_mod.math_batch("cos", x) - np.cos(x.astype(np.float64))).max() < 3e-7
+    u = rng.uniform(-1, 1, 4000).astype(np.float32)
+    assert np.abs(oracle_mod.math_batch("acos", u) - np.arccos(u.astype(np.float64))).max() < 1e-3
+    assert np.abs(oracle_mod.math_batch("asin", u) - np.arcsin(u.astype(np.float64))).max() < 1e-3
+    yx = rng.normal(size=(4000, 2)).astype(np.float32)
+    got = oracle_mod.math_batch("atan2", yx[:, 0], yx[:, 1])
+    assert np.abs(got - np.arctan2(yx[:, 0].astype(np.float64), yx[:, 1].astype(np.float64))).max() < 1e-3
+    p = rng.uniform(0, 1, 4000).astype(np.float32)
+    assert np.allclose(oracle_mod.math_batch("pow5", p), p.astype(np.float64) ** 5, rtol=1e-4, atol=1e-12)
+    assert oracle_mod.math_fn("pow5", 0.0) == 0.0 and oracle_mod.math_fn("pow5", 1.0) == 1.0
+    assert oracle_mod.math_fn("acos", 1.0) == 0.0 and np.isnan(oracle_mod.math_fn("acos", 2.0))
+    assert np.isfinite(oracle_mod.math_fn("atan2", 0.0, 0.0))
+    # the C-library back end clamps instead
+    assert oracle_mod.math_fn("acos", 2.0, libm=True) == 0.0
 
 
 def test_golden_ray_batches(oracle_mod):
-    for name in ("cubes", "_ObiWan"):
-        g = np.load(os.path.join(GOLDEN, "rays_%s.npz" % name))
+    # ids and (u, v, t) of the reference's findIntersection (run under llvmpipe), bit for bit
+    for name in ("cubes", "_ObiWan", "box", "sphere"):
+        g = np.load(os.path.join(GOLDEN, "ref_hits_%s.npz" % name))
         models, shadings, lights, materials = load_scene(name)
-        for libm in (False, True):      # hit decisions use + - * only: both back ends must agree exactly
+        for libm in (False, True):      # hit decisions use + - * / only: both back ends must agree exactly
             sc = oracle_mod.OracleScene(models, shadings, lights, materials, libm=libm)
             ids, uvt = sc.closest_hit_batch(g["o"], g["d"])
             assert np.array_equal(ids, g["ids"])
-            assert np.array_equal(uvt, g["uvt"], equal_nan=True)
+            hit = ids >= 0
+            assert np.array_equal(uvt[hit].view(np.uint32), g["uvt"][hit].view(np.uint32))
 
 
 def test_golden_images_and_backends(oracle_mod, cubes):
@@ -148,11 +146,12 @@ def test_golden_images_and_backends(oracle_mod, cubes):
         img, st = sc.render(cam, DEFAULT_CLOCK, 6, 1.0, 64, 64, 0, spp)
         assert np.array_equal(img, g["rgb_sum"])
         assert [st["pixel_samples"], st["rays"], st["shadow_probes"], st["glossy_probes"]] == g["stats"].tolist()
-        # C-library math differs by ulps in sin/cos/acos: a handful of samples may take another branch.
+        # C-library math differs from the GL implementation's approximations (acos/asin/atan by up to 1e-4):
+        # colours move by that much and a handful of samples take another branch.
         ref, _ = sl.render(cam, DEFAULT_CLOCK, 6, 1.0, 64, 64, 0, spp)
         rel_rmse = np.sqrt(np.mean((img - ref) ** 2)) / np.mean(ref)
         assert rel_rmse < 0.02, rel_rmse
-        assert np.mean(img != ref) < 0.05
+        assert np.mean(np.abs(img - ref) > 2e-3 * np.maximum(1.0, ref)) < 0.02
 
 
 def test_sum_chaining_stride_and_running_mean(oracle_mod, cubes):

@@ -1,0 +1,90 @@
+"""The CPU checker against vectors produced by the reference's own shader.
+
+tests/golden/ref_*.npz were written by tests/golden/make_glsl_reference_vectors.py, which runs the
+unmodified res/shader/raytracer.glsl under Mesa llvmpipe in the build container.  Everything here
+is compared bit for bit: GLSL leaves the rounding of its built-ins to the GL implementation, and
+the checker restates what that implementation does.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_scene
+
+IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close"]
+
+
+def same_bits(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+def expected_from_reference_colour(colour, sample):
+    """What the reference's main() stores on a cleared target for SAMPLE = sample (raytracer.glsl:609-616)."""
+    colour = np.ascontiguousarray(colour, dtype=np.float32)
+    if sample == 0:
+        return colour
+    inv = np.float32(1.0) / np.float32(sample + 1)
+    scale = np.float32(sample) * inv
+    return (np.float32(0.0) * scale + inv * colour).astype(np.float32)
+
+
+def test_builtins_equal_llvmpipe(oracle_mod):
+    g = np.load(os.path.join(GOLDEN, "ref_builtins.npz"))
+    x = g["x"]
+    for name in ("sin", "cos", "tan", "acos", "asin"):
+        assert same_bits(oracle_mod.math_batch(name, x), g[name]).all(), name
+    assert same_bits(oracle_mod.math_batch("pow5", x), g["pow5"]).all()
+    assert same_bits(oracle_mod.math_batch("pow5", (np.float32(1.0) - x).astype(np.float32)), g["pow5_1mx"]).all()
+    assert same_bits(oracle_mod.math_batch("atan2", x, np.float32(0.37)), g["atan2_x037"]).all()
+    assert same_bits(oracle_mod.math_batch("atan2", g["atan2_y"], g["atan2_x"]), g["atan2"]).all()
+    # the GL implementation's sqrt and 1/x are correctly rounded, inversesqrt is 1/sqrt with two roundings
+    pos = x > 0
+    assert same_bits(np.sqrt(x[pos]), g["sqrt"][pos]).all()
+    assert same_bits(np.float32(1.0) / x[pos], g["rcp"][pos]).all()
+    assert same_bits(np.float32(1.0) / np.sqrt(x[pos]), g["inversesqrt"][pos]).all()
+
+
+@pytest.mark.parametrize("key", ["pot", "npot"])
+def test_bilinear_lookup_equals_llvmpipe(oracle_mod, key):
+    g = np.load(os.path.join(GOLDEN, "ref_builtins.npz"))
+    models, shadings, lights, materials = load_scene("sphere")
+    sc = oracle_mod.OracleScene(models, shadings, lights, materials)
+    sc.upload_env(g["tex_%s_env" % key])
+    got = sc.sample_env(g["tex_%s_st" % key])
+    assert same_bits(got, g["tex_%s_rgb" % key]).all()
+
+
+@pytest.mark.parametrize("case", IMAGE_CASES)
+def test_images_equal_reference_shader(oracle_mod, case):
+    g = np.load(os.path.join(GOLDEN, "ref_image_%s.npz" % case))
+    models, shadings, lights, materials = load_scene(str(g["scene"]))
+    sc = oracle_mod.OracleScene(models, shadings, lights, materials)
+    sc.upload_env(g["env"])
+    cam, clock, recursion = g["camera"], int(g["clock"]), int(g["recursion"])
+    for s in g["samples"].tolist():
+        want = g["sample_%d" % s]
+        h, w = want.shape[:2]
+        colour, _ = sc.render(cam, clock, recursion, 1.0, w, h, s, 1)
+        got = expected_from_reference_colour(colour, s)
+        ok = same_bits(got, want).all(axis=2)
+        assert ok.all(), "%s SAMPLE %d: %d of %d pixels differ" % (case, s, int((~ok).sum()), ok.size)
+        # the checker's own running-mean mode does the same arithmetic
+        mean, _ = sc.render(cam, clock, recursion, 1.0, w, h, s, 1, mode="mean")
+        assert same_bits(mean, want).all()
+
+
+def test_running_mean_equals_reference_shader(oracle_mod):
+    g = np.load(os.path.join(GOLDEN, "ref_image_cubes.npz"))
+    models, shadings, lights, materials = load_scene("cubes")
+    sc = oracle_mod.OracleScene(models, shadings, lights, materials)
+    sc.upload_env(g["env"])
+    want = g["mean_16"]
+    h, w = want.shape[:2]
+    mean, _ = sc.render(g["camera"], int(g["clock"]), int(g["recursion"]), 1.0, w, h, 0, 16, mode="mean")
+    assert same_bits(mean, want).all()
+    # sums / n (what the product accumulates) equal the running mean up to the rounding of the accumulation
+    total, _ = sc.render(g["camera"], int(g["clock"]), int(g["recursion"]), 1.0, w, h, 0, 16)
+    assert np.allclose(total / 16.0, want, rtol=2e-5, atol=1e-6)
