@@ -197,25 +197,19 @@ void free_scene(rt_context *ctx) {
     ctx->have_scene = false;
 }
 
-// RGBA32F -> packed R11F_G11F_B10F.  Negative -> 0, NaN -> NaN, +Inf -> Inf, above the largest finite
-// value -> the largest finite value, otherwise round to nearest even (denormals kept).
+// RGBA32F -> packed R11F_G11F_B10F, the conversion of the texture upload at Scene.cpp:93-98.  OpenGL lets
+// the implementation pick either neighbouring value; Mesa: negative -> 0, NaN -> NaN, +Inf -> Inf, above
+// the largest finite value -> the largest finite value, below 2^-14 -> 0, otherwise the mantissa is truncated.
 __device__ uint32_t encode_ufloat(float f, int mbits) {
     const uint32_t bits = __float_as_uint(f);
     const uint32_t neg = bits >> 31, ex = (bits >> 23) & 0xFFu, man = bits & 0x7FFFFFu;
     const uint32_t top = (30u << mbits) | ((1u << mbits) - 1u);
     if (ex == 255u) return man ? ((31u << mbits) | 1u) : (neg ? 0u : (31u << mbits));
     if (neg) return 0u;
-    const int e = (int)ex - 112;                 // target biased exponent
-    if (e >= 31) return top;
-    uint32_t code;
-    if (e <= 0) {
-        code = (uint32_t)__float2int_rn(f * (float)(1u << (14 + mbits)));
-    } else {
-        const int sh = 23 - mbits;
-        const uint32_t keep = man >> sh, rest = man & ((1u << sh) - 1u), half = 1u << (sh - 1);
-        code = ((uint32_t)e << mbits) + keep + ((rest > half || (rest == half && (keep & 1u))) ? 1u : 0u);
-    }
-    return code > top ? top : code;
+    if (f > (mbits == 6 ? 65024.0f : 64512.0f)) return top;
+    const int e = (int)ex - 127;
+    if (e > -15) return ((uint32_t)(e + 15) << mbits) | (man >> (23 - mbits));
+    return 0u;
 }
 
 __global__ void k_pack_atlas(const float4 *__restrict__ src, uint32_t w, uint32_t h, uint32_t *__restrict__ dst,

@@ -10,10 +10,12 @@
  * createNewDrawable -> bindContext, GL entry points through libglapi's _glapi_get_proc_address.
  *
  * Modes
- *   image  <scene.rtscene> <env.f32> <env w> <env h> <W> <H> <clock> <recursion> <n_samples> <out.f32> <camera.f32> [first]
+ *   image  <scene.rtscene> <env.f32> <env w> <env h> <W> <H> <clock> <recursion> <n_samples> <out.f32> <camera.f32> [first [atlas.bin]]
  *          dispatches the shader for SAMPLE = first..first+n-1 (first defaults to 0) as Scene::traceScene does
  *          (Scene.cpp:423-433) on a zero-initialised target and writes the RGBA32F accumulation image (the
- *          shader's own running mean).
+ *          shader's own running mean).  atlas.bin: uint32 layer edge S, uint32 n uploads, then per upload uint32 material,
+ *          slot, w, h and w*h RGBA32F texels (uploaded as Scene::loadTexture does, Scene.cpp:93-98), then one int32
+ *          hasTexture flag per material.  Without it the atlas is a 1 x 1 x 3M array and no material is textured.
  *   hits   <scene.rtscene> <rays.f32 (n x 6: origin, direction)> <n> <out.bin (n x int32 id, then n x 3 float uvt)>
  *          runs a harness shader assembled at run time from the reference's own text (everything up to and
  *          including findIntersection, raytracer.glsl:1-235) plus a main() that calls findIntersection per ray.
@@ -149,6 +151,27 @@ int main(int argc, char **argv) {
     GLF(PFNGLMEMORYBARRIERPROC, glMemoryBarrier); GLF(PFN_GETTEXIMAGE, glGetTexImage);
     GLF(PFNGLGETUNIFORMLOCATIONPROC, glGetUniformLocation); GLF(PFN_FINISH, glFinish);
     GLF(PFN_GETERROR, glGetError);
+
+    if (!strcmp(argv[1], "pack")) {
+        /* pack <in.f32> <n texels, a multiple of 100> <out.f32>: what the GL implementation stores in a GL_R11F_G11F_B10F texture for
+         * RGBA float input (the conversion of Scene::loadTexture, Scene.cpp:93-98), read back as RGB float. */
+        const int n = atoi(argv[3]);
+        size_t got;
+        char *in = read_file(argv[2], &got);
+        if (got < 16ul * n) { fprintf(stderr, "input too short\n"); return 2; }
+        GLuint tex;
+        glGenTextures(1, &tex);
+        glBindTexture(GL_TEXTURE_2D, tex);
+        glTexStorage2D(GL_TEXTURE_2D, 1, GL_R11F_G11F_B10F, 100, n / 100);
+        glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, 100, n / 100, GL_RGBA, GL_FLOAT, in);
+        float *out = (float *)malloc(12ul * n);
+        glGetTexImage(GL_TEXTURE_2D, 0, GL_RGB, GL_FLOAT, out);
+        FILE *f = fopen(argv[4], "wb");
+        fwrite(out, 12, (size_t)n, f);
+        fclose(f);
+        fprintf(stderr, "pack: %d texels, gl error 0x%x\n", n, glGetError());
+        return 0;
+    }
 
     if (!strcmp(argv[1], "func")) {
         /* func <shader.glsl> <in.f32> <n_in_floats> <n_items> <out.f32> <out_floats_per_item> [ref|own [<env.f32> <w> <h>]]:
@@ -335,9 +358,34 @@ int main(int argc, char **argv) {
     /* atlas: sampler uniform location 1 on unit 1; a 1-texel array is enough for untextured scenes */
     glActiveTexture(GL_TEXTURE1);
     glBindTexture(GL_TEXTURE_2D_ARRAY, tex[2]);
-    glTexStorage3D(GL_TEXTURE_2D_ARRAY, 1, GL_R11F_G11F_B10F, 1, 1, (GLsizei)(3 * sc.n_mat));
+    {
+        GLF(PFNGLTEXSUBIMAGE3DPROC, glTexSubImage3D);
+        const char *atlas = argc > 14 ? read_file(argv[14], NULL) : NULL;
+        uint32_t S = 1, n_up = 0;
+        if (atlas) { memcpy(&S, atlas, 4); memcpy(&n_up, atlas + 4, 4); atlas += 8; }
+        glTexStorage3D(GL_TEXTURE_2D_ARRAY, 1, GL_R11F_G11F_B10F, (GLsizei)S, (GLsizei)S, (GLsizei)(3 * sc.n_mat));
+        /* storage contents are undefined: layers that are never uploaded read as zero */
+        float *zero = (float *)calloc((size_t)S * S, 16);
+        for (uint32_t l = 0; l < 3 * sc.n_mat; l++)
+            glTexSubImage3D(GL_TEXTURE_2D_ARRAY, 0, 0, 0, (GLint)l, (GLsizei)S, (GLsizei)S, 1, GL_RGBA, GL_FLOAT, zero);
+        free(zero);
+        for (uint32_t k = 0; k < n_up; k++) {
+            uint32_t hdr[4];
+            memcpy(hdr, atlas, 16);
+            atlas += 16;
+            glTexSubImage3D(GL_TEXTURE_2D_ARRAY, 0, 0, 0, (GLint)(hdr[0] * 3u + hdr[1]), (GLsizei)hdr[2], (GLsizei)hdr[3], 1,
+                            GL_RGBA, GL_FLOAT, atlas);
+            atlas += 16ul * hdr[2] * hdr[3];
+        }
+        if (atlas) {
+            glBindBuffer(GL_SHADER_STORAGE_BUFFER, bufs[3]);
+            glBufferData(GL_SHADER_STORAGE_BUFFER, 4l * sc.n_mat, atlas, GL_STATIC_DRAW);
+        }
+    }
     glTexParameteri(GL_TEXTURE_2D_ARRAY, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
     glTexParameteri(GL_TEXTURE_2D_ARRAY, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+    glTexParameteri(GL_TEXTURE_2D_ARRAY, GL_TEXTURE_WRAP_S, GL_REPEAT);
+    glTexParameteri(GL_TEXTURE_2D_ARRAY, GL_TEXTURE_WRAP_T, GL_REPEAT);
     glUniform1i(1, 1);
     glUniform1i(3, 2);                       /* IRRADIANCE: declared, never sampled by live code */
     glUniformMatrix4fv(4, 1, GL_FALSE, cam); /* CAMERA */

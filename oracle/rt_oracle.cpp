@@ -308,8 +308,9 @@ inline float uf_decode(uint32_t code, int mbits) {
     memcpy(&f, &bits, 4);
     return f;
 }
-// Encoding: negative -> 0, NaN -> NaN, +Inf -> Inf, above the largest finite value -> the largest
-// finite value, otherwise round to nearest even (denormals kept).
+// Encoding (the conversion of the texture upload, Scene.cpp:93-98; OpenGL allows either neighbouring value).
+// Mesa: negative -> 0, NaN -> NaN, +Inf -> Inf, above the largest finite value -> the largest finite value,
+// below 2^-14 -> 0, otherwise the mantissa is truncated.
 inline uint32_t uf_encode(float f, int mbits) {
     uint32_t bits;
     memcpy(&bits, &f, 4);
@@ -320,20 +321,10 @@ inline uint32_t uf_encode(float f, int mbits) {
         return sign ? 0u : (31u << mbits);
     }
     if (sign) return 0u;
-    const int E = (int)ex - 127 + 15;
-    if (E >= 31) return max_finite;
-    uint32_t code;
-    if (E <= 0) {
-        // denormal target: code = round(f * 2^(14 + mbits)); the product is exact in float
-        const float scaled = f * (float)(1u << (14 + mbits));
-        code = (uint32_t)nearbyintf(scaled);   // round-to-nearest-even in the default rounding mode
-    } else {
-        const int shift = 23 - mbits;
-        const uint32_t m = man >> shift, rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
-        const uint32_t up = (rem > half || (rem == half && (m & 1u))) ? 1u : 0u;
-        code = ((uint32_t)E << mbits) + m + up;
-    }
-    return code > max_finite ? max_finite : code;
+    if (f > (mbits == 6 ? 65024.0f : 64512.0f)) return max_finite;
+    const int E = (int)ex - 127;
+    if (E > -15) return ((uint32_t)(E + 15) << mbits) | (man >> (23 - mbits));
+    return 0u;
 }
 inline uint32_t pack_r11g11b10(float r, float g, float b) {
     return uf_encode(r, 6) | (uf_encode(g, 6) << 11) | (uf_encode(b, 5) << 22);

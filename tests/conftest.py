@@ -39,6 +39,26 @@ def load_scene(name):
     return read_rtscene(os.path.join(SCENES, name + ".rtscene"))
 
 
+def textured_cubes(atlas_size=32):
+    """The `cubes` scene with synthetic texture coordinates and tangents on every triangle and synthetic albedo /
+    normal / ARM layers for material 2 (the ARM layer smaller than the atlas: it fills a corner only).
+    Returns (scene tuple, layers {slot: rgba}, hasTexture flags)."""
+    models, shadings, lights, materials = load_scene("cubes")
+    rng = np.random.default_rng(5)
+    S = atlas_size
+    shadings = shadings.copy()
+    shadings["tex_p"] = rng.uniform(0, 1, size=(len(shadings), 2)).astype(np.float32)
+    shadings["tex_u"] = rng.uniform(-2, 2, size=(len(shadings), 2)).astype(np.float32)
+    shadings["tex_v"] = rng.uniform(-2, 2, size=(len(shadings), 2)).astype(np.float32)
+    t = rng.normal(size=(len(shadings), 3, 3)).astype(np.float32)
+    shadings["tangents"] = t / np.linalg.norm(t, axis=2, keepdims=True)
+    albedo = rng.uniform(0.1, 0.9, size=(S, S, 4)).astype(np.float32)
+    nrm = rng.uniform(0.3, 0.7, size=(S, S, 4)).astype(np.float32)
+    nrm[..., 2] = rng.uniform(0.8, 1.0, size=(S, S))
+    arm = rng.uniform(0.05, 1.0, size=(S * 3 // 4, S * 5 // 8, 4)).astype(np.float32)
+    return (models, shadings, lights, materials), {0: albedo, 1: nrm, 2: arm}, np.array([0, 0, 1, 0], np.int32)
+
+
 @pytest.fixture(scope="session")
 def cubes():
     return load_scene("cubes")

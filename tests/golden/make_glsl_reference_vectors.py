@@ -14,7 +14,13 @@ Writes tests/golden/ref_*.npz; nothing of the reference's text is stored, only i
   ref_image_<case>.npz   the image the reference's main() writes for single SAMPLE values on a cleared target
                      (for SAMPLE = S > 0 that is colour * 1/(S+1), raytracer.glsl:609-613), and for the
                      cubes case also the running mean over SAMPLE 0..15
+  ref_c1_cubes512.json   the reference's own CPU-runnable configuration (cubes, 512 x 512, SAMPLE 0..15): SHA-256
+                     of the RGB float32 bytes of each single-SAMPLE image and of the 16-sample running mean
+                     (results are compared bit for bit, so a digest is enough), and llvmpipe's wall time
 """
+import hashlib
+import json
+import time
 import os
 import subprocess
 import sys
@@ -25,7 +31,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(HERE, ".."))
-from conftest import constant_env, gradient_env, load_scene  # noqa: E402
+from conftest import constant_env, gradient_env, load_scene, textured_cubes  # noqa: E402
+from gpuraytracer_amd.scene_io import write_rtscene  # noqa: E402
 from gpuraytracer_amd.camera import camera_matrix, DEFAULT_CLOCK  # noqa: E402
 from make_golden_vectors import ray_batch  # noqa: E402
 
@@ -69,12 +76,26 @@ def ref_hits(scene, o, d):
     return raw[:4 * n].view(np.int32).copy(), raw[4 * n:].view(np.float32).reshape(n, 3).copy()
 
 
-def ref_image(scene, env, width, height, clock, recursion, first, count, cam):
+def ref_image(scene, env, width, height, clock, recursion, first, count, cam, atlas=None):
+    """scene: name of a bundled scene or path of an rtscene file; atlas: path of an atlas description."""
     np.ascontiguousarray(env, dtype=np.float32).tofile(tmp("env.f32"))
     np.ascontiguousarray(cam, dtype=np.float32).tofile(tmp("cam.f32"))
-    run("image", scene_path(scene), tmp("env.f32"), env.shape[1], env.shape[0], width, height, clock, recursion,
-        count, tmp("img.f32"), tmp("cam.f32"), first)
+    args = ["image", scene if os.path.sep in scene else scene_path(scene), tmp("env.f32"), env.shape[1], env.shape[0],
+            width, height, clock, recursion, count, tmp("img.f32"), tmp("cam.f32"), first]
+    if atlas:
+        args.append(atlas)
+    run(*args)
     return np.fromfile(tmp("img.f32"), dtype=np.float32).reshape(height, width, 4)[..., :3].copy()
+
+
+def write_atlas(path, size, uploads, flags):
+    """uploads: list of (material, slot, rgba[h, w, 4])."""
+    with open(path, "wb") as f:
+        f.write(np.array([size, len(uploads)], dtype=np.uint32).tobytes())
+        for material, slot, rgba in uploads:
+            f.write(np.array([material, slot, rgba.shape[1], rgba.shape[0]], dtype=np.uint32).tobytes())
+            f.write(np.ascontiguousarray(rgba, dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(flags, dtype=np.int32).tobytes())
 
 
 # (case name, scene, environment, env name, width, height, RECURSION, camera translation/rotation, SAMPLE values)
@@ -114,6 +135,14 @@ def main():
         tex["tex_%s_env" % key] = env
         tex["tex_%s_st" % key] = st
         tex["tex_%s_rgb" % key] = ref_func("env_lookup.glsl", st, len(st), 3, env=env)
+    # the conversion of an RGBA float upload to GL_R11F_G11F_B10F
+    px = np.concatenate([rng.uniform(0, 2, 5000), 10 ** rng.uniform(-7, 5.2, 4988),
+                         [0, -1, 1e-8, 6.1e-5, 6.0e-5, 3e-5, 65024, 65025, 70000, 1e9, np.inf, np.nan]]).astype(np.float32)
+    rgba = np.stack([px, px, px, np.ones_like(px)], axis=1)
+    rgba.tofile(tmp("pack.f32"))
+    run("pack", tmp("pack.f32"), len(px), tmp("pack_out.f32"))
+    tex["pack_x"] = px
+    tex["pack_rgb"] = np.fromfile(tmp("pack_out.f32"), dtype=np.float32).reshape(len(px), 3)
     np.savez_compressed(os.path.join(HERE, "ref_builtins.npz"), x=x, sin=b1[:, 0], cos=b1[:, 1], pow5=b1[:, 2],
                         tan=b1[:, 3], acos=b1[:, 4], asin=b1[:, 5], atan2_x037=b1[:, 6], sqrt=b1[:, 7],
                         inversesqrt=b1[:, 8], rcp=b1[:, 9], log2=b2[:, 0], exp2=b2[:, 1], pow24=b2[:, 2],
@@ -139,6 +168,37 @@ def main():
             out["mean_16"] = ref_image(scene, env, width, height, DEFAULT_CLOCK, recursion, 0, 16, cam)
         np.savez_compressed(os.path.join(HERE, "ref_image_%s.npz" % case), **out)
         print("image %-22s %dx%d RECURSION %d SAMPLE %s" % (case, width, height, recursion, list(samples)))
+
+    # --- textured materials: the atlas path (three layers of material 2, LINEAR + REPEAT on R11F_G11F_B10F)
+    scene, layers, flags = textured_cubes(32)
+    write_rtscene(tmp("textured.rtscene"), *scene)
+    write_atlas(tmp("atlas.bin"), 32, [(2, k, layers[k]) for k in (0, 1, 2)], flags)
+    cam = camera_matrix()
+    env = gradient_env()
+    out = {"env": env, "camera": cam, "clock": np.uint32(4242), "recursion": np.int32(6),
+           "samples": np.array([0, 1, 2, 3], dtype=np.uint32), "atlas_size": np.uint32(32)}
+    for s in (0, 1, 2, 3):
+        out["sample_%d" % s] = ref_image(tmp("textured.rtscene"), env, 48, 32, 4242, 6, s, 1, cam, atlas=tmp("atlas.bin"))
+    np.savez_compressed(os.path.join(HERE, "ref_image_cubes_textured.npz"), **out)
+    print("image cubes_textured         48x32 RECURSION 6 SAMPLE [0, 1, 2, 3]")
+
+    # --- the reference's CPU-runnable configuration, as digests
+    cam = camera_matrix()
+    env = constant_env()
+    c1 = {"scene": "cubes", "width": 512, "height": 512, "clock": DEFAULT_CLOCK, "recursion": 6,
+          "environment": "constant_env()", "samples": list(range(16)), "sha256_sample": []}
+    for s in range(16):
+        img = ref_image("cubes", env, 512, 512, DEFAULT_CLOCK, 6, s, 1, cam)
+        c1["sha256_sample"].append(hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest())
+    t0 = time.time()
+    mean = ref_image("cubes", env, 512, 512, DEFAULT_CLOCK, 6, 0, 16, cam)
+    c1["llvmpipe_seconds_16spp"] = round(time.time() - t0, 3)
+    c1["llvmpipe_threads"] = os.cpu_count()
+    c1["sha256_mean_16"] = hashlib.sha256(np.ascontiguousarray(mean).tobytes()).hexdigest()
+    c1["mean_radiance_16"] = float(mean.mean())
+    with open(os.path.join(HERE, "ref_c1_cubes512.json"), "w") as f:
+        json.dump(c1, f, indent=1)
+    print("C1 digests written; llvmpipe: %.2f s for 16 spp on %d threads" % (c1["llvmpipe_seconds_16spp"], os.cpu_count()))
     for f in os.listdir(TMP):
         os.remove(os.path.join(TMP, f))
 

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, constant_env, gradient_env, load_scene
+from conftest import GOLDEN, constant_env, gradient_env, load_scene, textured_cubes
 from gpuraytracer_amd.camera import camera_matrix, DEFAULT_CLOCK
 
 pytestmark = pytest.mark.gpu
@@ -133,6 +133,23 @@ def test_images_equal_reference_shader(gpu_ctx, case, pipeline):
         assert same.all(), "%s SAMPLE %d pipeline %d: %d pixels differ" % (case, s, pipeline, int((~same.all(axis=2)).sum()))
 
 
+def test_c1_digests_equal_reference_shader(gpu_ctx):
+    """cubes, 512 x 512, SAMPLE 0..15 (the reference's own CPU-runnable configuration) at full size against the
+    SHA-256 digests of the images the reference's shader wrote for each SAMPLE."""
+    import hashlib
+    import json
+    with open(os.path.join(GOLDEN, "ref_c1_cubes512.json")) as f:
+        c1 = json.load(f)
+    _upload(gpu_ctx, load_scene(c1["scene"]), constant_env())
+    for s in c1["samples"]:
+        colour, _ = _render(gpu_ctx, c1["width"], c1["height"], s, 1, recursion=c1["recursion"], clock=c1["clock"])
+        got = colour
+        if s > 0:
+            inv = np.float32(1.0) / np.float32(s + 1)
+            got = (np.float32(0.0) * (np.float32(s) * inv) + inv * colour).astype(np.float32)
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == c1["sha256_sample"][s], s
+
+
 def test_mean_equals_reference_running_mean(gpu_ctx):
     # 16 samples: sum / 16 against the reference's running mean; the two accumulate in different orders
     g = np.load(os.path.join(GOLDEN, "ref_image_cubes.npz"))
@@ -216,38 +233,37 @@ def test_launch_chaining_and_sample_split(gpu_ctx, cubes):
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
 
 
-def test_textured_materials_bit_exact(gpu_ctx, oracle_mod, cubes):
-    # synthetic albedo / normal / ARM layers on the Wall material, small atlas
-    models, shadings, lights, materials = cubes
-    rng = np.random.default_rng(5)
-    S = 32
-    # give the triangles texture coordinates that span the layer
-    shadings = shadings.copy()
-    shadings["tex_p"] = rng.uniform(0, 1, size=(len(shadings), 2)).astype(np.float32)
-    shadings["tex_u"] = rng.uniform(-2, 2, size=(len(shadings), 2)).astype(np.float32)
-    shadings["tex_v"] = rng.uniform(-2, 2, size=(len(shadings), 2)).astype(np.float32)
-    t = rng.normal(size=(len(shadings), 3, 3)).astype(np.float32)
-    shadings["tangents"] = t / np.linalg.norm(t, axis=2, keepdims=True)
-    albedo = rng.uniform(0.1, 0.9, size=(S, S, 4)).astype(np.float32)
-    nrm = rng.uniform(0.3, 0.7, size=(S, S, 4)).astype(np.float32)
-    nrm[..., 2] = rng.uniform(0.8, 1.0, size=(S, S))
-    arm = rng.uniform(0.05, 1.0, size=(24, 20, 4)).astype(np.float32)     # smaller than the layer: corner only
+def test_textured_materials_bit_exact(gpu_ctx, oracle_mod):
+    # synthetic albedo / normal / ARM layers on one material, small atlas: against the images of the reference's
+    # shader (single SAMPLE values) and against the checker (4-sample sums and counters)
+    g = np.load(os.path.join(GOLDEN, "ref_image_cubes_textured.npz"))
+    S = int(g["atlas_size"])
+    (models, shadings, lights, materials), layers, flags = textured_cubes(S)
     gpu_ctx.upload_scene(models, shadings, lights, materials)
-    gpu_ctx.upload_env(gradient_env())
+    gpu_ctx.upload_env(g["env"])
     gpu_ctx.set_atlas_size(S)
     sc = oracle_mod.OracleScene(models, shadings, lights, materials)
-    sc.upload_env(gradient_env())
+    sc.upload_env(g["env"])
     sc.set_atlas_size(S)
     for target in (gpu_ctx, sc):
-        target.upload_atlas_layer(2, 0, albedo)
-        target.upload_atlas_layer(2, 1, nrm)
-        target.upload_atlas_layer(2, 2, arm)
-        target.set_has_texture(np.array([0, 0, 1, 0], np.int32))
-    want, wst = sc.render(CAM, 4242, 6, 1.0, 48, 32, 0, 4)
+        for k in (0, 1, 2):
+            target.upload_atlas_layer(2, k, layers[k])
+        target.set_has_texture(flags)
+    clock, recursion = int(g["clock"]), int(g["recursion"])
+    want, wst = sc.render(g["camera"], clock, recursion, 1.0, 48, 32, 0, 4)
     for pipeline in (0, 1, 2, 3):
-        img, st = _render(gpu_ctx, 48, 32, 0, 4, clock=4242, pipeline=pipeline)
+        img, st = _render(gpu_ctx, 48, 32, 0, 4, clock=clock, recursion=recursion, pipeline=pipeline, cam=g["camera"])
         assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
         assert st["rays"] == wst["rays"]
+        for s in g["samples"].tolist():
+            ref = g["sample_%d" % s]
+            colour, _ = _render(gpu_ctx, 48, 32, s, 1, clock=clock, recursion=recursion, pipeline=pipeline, cam=g["camera"])
+            got = colour
+            if s > 0:
+                inv = np.float32(1.0) / np.float32(s + 1)
+                got = (np.float32(0.0) * (np.float32(s) * inv) + inv * colour).astype(np.float32)
+            same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+            assert same.all(), (pipeline, s)
     gpu_ctx.set_atlas_size(4096)
 
 

@@ -88,3 +88,50 @@ def test_running_mean_equals_reference_shader(oracle_mod):
     # sums / n (what the product accumulates) equal the running mean up to the rounding of the accumulation
     total, _ = sc.render(g["camera"], int(g["clock"]), int(g["recursion"]), 1.0, w, h, 0, 16)
     assert np.allclose(total / 16.0, want, rtol=2e-5, atol=1e-6)
+
+
+def test_c1_digests_equal_reference_shader(oracle_mod):
+    """The reference's CPU-runnable configuration (cubes, 512 x 512, SAMPLE 0..15) at full size: SHA-256 of
+    every single-SAMPLE image and of the 16-sample running mean the reference wrote."""
+    import hashlib
+    import json
+    with open(os.path.join(GOLDEN, "ref_c1_cubes512.json")) as f:
+        c1 = json.load(f)
+    from conftest import constant_env
+    from gpuraytracer_amd.camera import camera_matrix
+    models, shadings, lights, materials = load_scene(c1["scene"])
+    sc = oracle_mod.OracleScene(models, shadings, lights, materials)
+    sc.upload_env(constant_env())
+    cam, w, h = camera_matrix(), c1["width"], c1["height"]
+    for s in (0, 1, 15):           # the GPU test covers all sixteen
+        colour, _ = sc.render(cam, c1["clock"], c1["recursion"], 1.0, w, h, s, 1)
+        got = expected_from_reference_colour(colour, s)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == c1["sha256_sample"][s], s
+    mean, _ = sc.render(cam, c1["clock"], c1["recursion"], 1.0, w, h, 0, 16, mode="mean")
+    assert hashlib.sha256(mean.tobytes()).hexdigest() == c1["sha256_mean_16"]
+
+
+def test_packed_float_upload_equals_gl(oracle_mod):
+    # what the GL implementation stores in a GL_R11F_G11F_B10F texel for an RGBA float upload (Scene.cpp:93-98)
+    g = np.load(os.path.join(GOLDEN, "ref_builtins.npz"))
+    x, want = g["pack_x"], g["pack_rgb"]
+    got = np.array([oracle_mod.unpack_r11g11b10(oracle_mod.pack_r11g11b10(float(v), float(v), float(v))) for v in x])
+    assert same_bits(got, want).all()
+
+
+def test_textured_images_equal_reference_shader(oracle_mod):
+    # atlas path: texture coordinates, tangent frame, normal map, ARM layer, 11/11/10-bit texels
+    from conftest import textured_cubes
+    g = np.load(os.path.join(GOLDEN, "ref_image_cubes_textured.npz"))
+    scene, layers, flags = textured_cubes(int(g["atlas_size"]))
+    sc = oracle_mod.OracleScene(*scene)
+    sc.upload_env(g["env"])
+    sc.set_atlas_size(int(g["atlas_size"]))
+    for k in (0, 1, 2):
+        sc.upload_atlas_layer(2, k, layers[k])
+    sc.set_has_texture(flags)
+    for s in g["samples"].tolist():
+        want = g["sample_%d" % s]
+        h, w = want.shape[:2]
+        mean, _ = sc.render(g["camera"], int(g["clock"]), int(g["recursion"]), 1.0, w, h, s, 1, mode="mean")
+        assert same_bits(mean, want).all(), s
