@@ -37,7 +37,7 @@ struct rt_context {
     bool have_scene = false;
 
     // hierarchies (all triangles; light triangles only), see rt_bvh.h
-    struct DevBvh { float4 *nodes = nullptr, *leaf_geo = nullptr; int *leaf_ids = nullptr; float max_abs = 0.0f; bool ok = false; };
+    struct DevBvh { float4 *nodes = nullptr, *leaf_geo = nullptr; int *leaf_ids = nullptr; float max_abs = 0.0f; int n_nodes = 0; bool ok = false; };
     DevBvh bvh, light_bvh;
     int accel = -1;            // -1 auto (hierarchy from ACCEL_AUTO_MIN triangles on), 0 brute force, 1 hierarchy
 
@@ -122,6 +122,7 @@ DBvh device_bvh(const rt_context *ctx, const rt_context::DevBvh &b, bool want) {
     d.leaf_ids = b.leaf_ids;
     d.max_abs_coord = b.max_abs;
     d.enabled = (want && b.ok) ? 1 : 0;
+    d.n_nodes = b.n_nodes;
     (void)ctx;
     return d;
 }
@@ -151,6 +152,7 @@ hipError_t upload_bvh(const rt_triangle_model *tris, uint32_t count, rt_context:
     if (e == hipSuccess && !hb.leaf_ids.empty())
         e = hipMemcpy(out.leaf_ids, hb.leaf_ids.data(), hb.leaf_ids.size() * sizeof(int), hipMemcpyHostToDevice);
     out.max_abs = hb.max_abs_coord;
+    out.n_nodes = (int)(hb.nodes.size() / 16);
     out.ok = e == hipSuccess;
     return e;
 }
@@ -595,7 +597,7 @@ int rt_closest_hit_batch_device(rt_context *ctx, const float *o_xyz, const float
     if (bind_device(ctx)) return RT_ERR_DEVICE;
     const DScene sc = device_scene(ctx);
     if (use_accel(ctx))
-        hipLaunchKernelGGL(k_closest_hit_batch_bvh, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, sc,
+        hipLaunchKernelGGL(k_closest_hit_batch_bvh, dim3((unsigned)std::min<uint64_t>((n + 63) / 64, 4096)), dim3(64), 0, ctx->stream, sc,
                            device_bvh(ctx, ctx->bvh, true), o_xyz, d_xyz, (unsigned long long)n, id, uvt, ctx->d_stats);
     else
         hipLaunchKernelGGL(k_closest_hit_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sc, o_xyz,

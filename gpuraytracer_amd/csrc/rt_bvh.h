@@ -41,13 +41,37 @@ struct DBvh {
     const int *leaf_ids;
     float max_abs_coord;
     int enabled;
+    int n_nodes;
 };
 
-constexpr int BVH_STACK = 32;
+#ifndef RT_BVH_STACK
+#define RT_BVH_STACK 32
+#endif
+constexpr int BVH_STACK = RT_BVH_STACK;
 constexpr float BVH_NEAR = 1.0f + 1.0f / 4096.0f;    // 2^-12 depth margin
+constexpr int BVH_TOP_NODES = 256;                   // nodes nearest the root that a workgroup keeps in LDS (16 KB)
+
+// Per-lane traversal state that lives in LDS: this lane's column of a stack array [BVH_STACK][64], and the
+// workgroup's copy of the first n_top nodes of the hierarchy (breadth-first order, so these are the levels
+// nearest the root).  Fetching those from LDS takes the most frequent node reads off the vector memory
+// path, which is the busiest unit of the traversal kernels.
+typedef const __attribute__((address_space(3))) v4f *lds_v4f_ptr;
+struct BvhScratch {
+    int *stack;
+    lds_v4f_ptr top;      // LDS address space: the reads become ds_read_b128, not generic-address loads
+    int n_top;
+};
+
+// Cooperative copy of the top of the hierarchy into LDS; every thread of the workgroup calls it.
+RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top) {
+    const int n_top = bv.enabled ? (bv.n_nodes < BVH_TOP_NODES ? bv.n_nodes : BVH_TOP_NODES) : 0;
+    for (int i = threadIdx.x; i < n_top * 4; i += blockDim.x) top[i] = ((const v4f *)bv.nodes)[i];
+    __syncthreads();
+    return n_top;
+}
 
 struct BvhRay {
-    f3 o_lo, o_hi;   // origin shifted by -r / +r: (box.lo - o_hi) and (box.hi - o_lo) widen the box by r
+    f3 oi_lo, oi_hi;   // (origin -r) * inv and (origin + r) * inv: lo*inv - oi_hi and hi*inv - oi_lo widen the box by r
     f3 inv;
     bool finite;
 };
@@ -57,22 +81,23 @@ RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
     const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y)),
                                     __builtin_fmaxf(__builtin_fabsf(ray.o.z), max_abs_coord));
     const float r = m * (1.0f / 65536.0f) + 1e-30f;
-    b.o_lo = mk3(ray.o.x - r, ray.o.y - r, ray.o.z - r);
-    b.o_hi = mk3(ray.o.x + r, ray.o.y + r, ray.o.z + r);
     // reciprocal to 1 ulp: the slab test is conservative by far more than that
     b.inv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
+    b.oi_lo = mk3((ray.o.x - r) * b.inv.x, (ray.o.y - r) * b.inv.y, (ray.o.z - r) * b.inv.z);
+    b.oi_hi = mk3((ray.o.x + r) * b.inv.x, (ray.o.y + r) * b.inv.y, (ray.o.z + r) * b.inv.z);
     const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
     b.finite = (s - s) == 0.0f;      // false when any component is NaN or infinite
     return b;
 }
 
-// Slab test against a box widened by r.  Returns the entry distance (clamped at 0) or a negative
-// value when the box is missed or lies beyond `t_max`.  min/max ignore NaN (0 * inf on a slab
-// boundary), which errs on the side of visiting.
+// Slab test against a box widened by r (one fused multiply-add per plane; this test only has to be
+// conservative, it takes no part in the hit arithmetic).  Returns the entry distance (clamped at 0) or a
+// negative value when the box is missed or lies beyond `t_max`.  min/max ignore NaN (inf - inf for a ray
+// parallel to a slab), which errs on the side of visiting.
 RT_DEV float box_entry(const BvhRay &br, f3 lo, f3 hi, float t_max) {
-    const float ax = (lo.x - br.o_hi.x) * br.inv.x, bx = (hi.x - br.o_lo.x) * br.inv.x;
-    const float ay = (lo.y - br.o_hi.y) * br.inv.y, by = (hi.y - br.o_lo.y) * br.inv.y;
-    const float az = (lo.z - br.o_hi.z) * br.inv.z, bz = (hi.z - br.o_lo.z) * br.inv.z;
+    const float ax = __builtin_fmaf(lo.x, br.inv.x, -br.oi_hi.x), bx = __builtin_fmaf(hi.x, br.inv.x, -br.oi_lo.x);
+    const float ay = __builtin_fmaf(lo.y, br.inv.y, -br.oi_hi.y), by = __builtin_fmaf(hi.y, br.inv.y, -br.oi_lo.y);
+    const float az = __builtin_fmaf(lo.z, br.inv.z, -br.oi_hi.z), bz = __builtin_fmaf(hi.z, br.inv.z, -br.oi_lo.z);
     float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
                                __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
     float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
@@ -86,10 +111,10 @@ struct BvhCounters { uint32_t nodes, tris; };
 
 // Generic traversal.  `leaf(slot)` is called for every triangle slot of every leaf whose box the ray
 // enters within t_limit(); it returns false to stop the whole traversal (any-hit found).
-// `stack` points at this lane's column of an LDS array [BVH_STACK][64].
 template <typename LeafFn, typename LimitFn>
-RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, int *stack, LeafFn leaf, LimitFn t_limit,
+RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const BvhScratch &ws, LeafFn leaf, LimitFn t_limit,
                          BvhCounters &cnt) {
+    int *stack = ws.stack;
     int sp = 0;
     int node = 0;
     bool run = active;
@@ -99,30 +124,34 @@ RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, int *sta
     while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
         while (__builtin_amdgcn_ballot_w64(run && node >= 0) != 0ull) {
             if (run && node >= 0) {
-                const float4 q0 = bv.nodes[4 * node + 0], q1 = bv.nodes[4 * node + 1], q2 = bv.nodes[4 * node + 2],
-                             q3 = bv.nodes[4 * node + 3];
+                v4f q0, q1, q2, q3;
+                if (node < ws.n_top) {
+                    q0 = ws.top[4 * node + 0]; q1 = ws.top[4 * node + 1]; q2 = ws.top[4 * node + 2]; q3 = ws.top[4 * node + 3];
+                } else {
+                    const v4f *g = (const v4f *)bv.nodes;
+                    q0 = g[4 * node + 0]; q1 = g[4 * node + 1]; q2 = g[4 * node + 2]; q3 = g[4 * node + 3];
+                }
                 cnt.nodes++;
                 const float lim = t_limit();
                 const float e0 = box_entry(br, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), lim);
                 const float e1 = box_entry(br, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), lim);
                 const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
                 const bool h0 = e0 >= 0.0f, h1 = e1 >= 0.0f;
-                if (h0 & h1) {
-                    const bool first0 = e0 <= e1;
-                    stack[64 * sp] = first0 ? c1 : c0;
-                    sp++;
-                    node = first0 ? c0 : c1;
-                } else if (h0 | h1) {
-                    node = h0 ? c0 : c1;
-                } else if (sp > 0) {
-                    sp--;
-                    node = stack[64 * sp];
-                } else {
-                    run = false;
-                }
+                const bool both = h0 & h1, none = !(h0 | h1);
+                const bool first0 = e0 <= e1;
+                // the child to descend into: the nearer one of two, or the only one entered
+                const int near = (both ? first0 : h0) ? c0 : c1;
+                if (both) stack[64 * sp] = first0 ? c1 : c0;
+                sp += both ? 1 : 0;
+                const bool pop = none & (sp > 0);
+                sp -= pop ? 1 : 0;
+                int next = near;
+                if (pop) next = stack[64 * sp];
+                run = !none | pop;
+                node = next;
             }
         }
-        if (run) {      // node < 0: a leaf
+        if (run && node < 0) {      // a leaf
             const int code = ~node;
             const int first = code >> 3, n = code & 7;
             bool go_on = true;
@@ -140,10 +169,12 @@ RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, int *sta
     }
 }
 
-RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot, int &id) {
-    const float4 a = bv.leaf_geo[4 * slot + 0], b = bv.leaf_geo[4 * slot + 1], c = bv.leaf_geo[4 * slot + 2],
-                 d = bv.leaf_geo[4 * slot + 3];
-    id = __float_as_int(d.x);
+// The triangle record of a leaf slot (3 of the 4 float4 of the slot).  Its index is the first word of the
+// fourth float4; callers fetch it with leaf_tri_id only for triangles that passed their test, so the common
+// case costs three vector loads instead of four.
+RT_DEV int leaf_tri_id(const DBvh &bv, int slot) { return __float_as_int(bv.leaf_geo[4 * slot + 3].x); }
+RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot) {
+    const float4 a = bv.leaf_geo[4 * slot + 0], b = bv.leaf_geo[4 * slot + 1], c = bv.leaf_geo[4 * slot + 2];
     Tri t;
     t.n = mk3(a.x, a.y, a.z);
     t.p = mk3(a.w, b.x, b.y);
@@ -157,7 +188,7 @@ RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot, int &id) {
 // `current` is skipped.  Returns the triangle id or -1; isec = (x, y, rd, det) of the winner, or
 // (0, 0, -1, w_init) when nothing was hit.
 RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, int begin_id, int end_id,
-                           int current, float w_init, int *stack, f4 &isec, BvhCounters &cnt) {
+                           int current, float w_init, const BvhScratch &ws, f4 &isec, BvhCounters &cnt) {
     const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
     int best = -1;
     float t_min = __builtin_inff();
@@ -165,9 +196,7 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
     f4 st;
     st.x = 0.0f; st.y = 0.0f; st.z = -1.0f; st.w = w_init;
     auto leaf = [&](int slot) -> bool {
-        int id;
-        const Tri t = load_leaf_tri(bv, slot, id);
-        if (id < begin_id || id >= end_id || id == current) return true;
+        const Tri t = load_leaf_tri(bv, slot);
         const float det = -dot(ray.d, t.n);
         const f3 delta = ray.o - t.p;
         const float rd = dot(t.n, delta);
@@ -176,6 +205,8 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
         pt.det = det; pt.rd = rd; pt.delta = delta;
         float rx, ry;
         if (!inside_test(ray, t, pt, rx, ry)) return true;
+        const int id = leaf_tri_id(bv, slot);
+        if (id < begin_id || id >= end_id || id == current) return true;
         // a candidate: rule 3 between it and the running best
         bool take;
         if (best < 0) take = true;
@@ -189,7 +220,7 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
         return true;
     };
     auto limit = [&]() -> float { return t_min * BVH_NEAR; };
-    bvh_traverse(bv, br, active && br.finite, stack, leaf, limit, cnt);
+    bvh_traverse(bv, br, active && br.finite, ws, leaf, limit, cnt);
 
     // Rare cases, redone by the index-order loop: three or more candidates within the margin of the
     // closest depth, or a non-finite ray.
@@ -207,20 +238,18 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
 // sampleLight's occlusion query (raytracer.glsl:372-378): is any triangle != current hit by
 // intersectTriangleShadow within max_t?
 RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
-                               int *stack, BvhCounters &cnt) {
+                               const BvhScratch &ws, BvhCounters &cnt) {
     const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
     const bool ok = br.finite && ((max_t - max_t) == 0.0f);
     bool blocked = false;
     auto leaf = [&](int slot) -> bool {
-        int id;
-        const Tri t = load_leaf_tri(bv, slot, id);
-        if (id == current) return true;
-        if (intersect_triangle_shadow(ray, t, max_t)) { blocked = true; return false; }
+        const Tri t = load_leaf_tri(bv, slot);
+        if (intersect_triangle_shadow(ray, t, max_t) && leaf_tri_id(bv, slot) != current) { blocked = true; return false; }
         return true;
     };
     const float lim = max_t * BVH_NEAR;
     auto limit = [&]() -> float { return lim; };
-    bvh_traverse(bv, br, active && ok, stack, leaf, limit, cnt);
+    bvh_traverse(bv, br, active && ok, ws, leaf, limit, cnt);
     const bool redo = active && !ok;
     if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
         const bool b2 = shadow_any_hit_bf(sc, ray, max_t, current, redo);
@@ -232,7 +261,7 @@ RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
 // Second phase of sampleLightGlossy (raytracer.glsl:406-419): does any triangle of [lights, count)
 // other than `current` pass intersectTriangle against the fixed state `isec`?
 RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, const f4 &isec, int current, bool active,
-                               int *stack, BvhCounters &cnt) {
+                               const BvhScratch &ws, BvhCounters &cnt) {
     const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
     const bool bounded = isec.z >= 0.0f;                 // a light was hit: only triangles not farther than it matter
     const float t_light = isec.z / isec.w;
@@ -240,17 +269,18 @@ RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
     bool blocked = false;
     const int lights = sc.lights;
     auto leaf = [&](int slot) -> bool {
-        int id;
-        const Tri t = load_leaf_tri(bv, slot, id);
-        if (id < lights || id == current) return true;
+        const Tri t = load_leaf_tri(bv, slot);
         PlaneTest pt;
         float rx, ry;
-        if (plane_test_closest(ray, t, isec, pt) && inside_test(ray, t, pt, rx, ry)) { blocked = true; return false; }
+        if (plane_test_closest(ray, t, isec, pt) && inside_test(ray, t, pt, rx, ry)) {
+            const int id = leaf_tri_id(bv, slot);
+            if (id >= lights && id != current) { blocked = true; return false; }
+        }
         return true;
     };
     const float lim = bounded ? t_light * BVH_NEAR : __builtin_inff();
     auto limit = [&]() -> float { return lim; };
-    bvh_traverse(bv, br, active && ok, stack, leaf, limit, cnt);
+    bvh_traverse(bv, br, active && ok, ws, leaf, limit, cnt);
     const bool redo = active && !ok;
     if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
         const bool b2 = closer_any_hit_range(sc.geo, lights < sc.count ? lights : sc.count, sc.count, ray, isec, current, redo);
@@ -260,46 +290,59 @@ RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
 }
 
 // sampleLightGlossy's search (raytracer.glsl:403-419) in its two-phase form, see glossy_search_bf.
-// `lbv` is a hierarchy over the light triangles [0, lights) alone.
+// `lbv` is a hierarchy over the light triangles [0, lights) alone; the LDS copy in `ws` belongs to `bv`.
 RT_DEV int glossy_search_bvh(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &ray, int current, bool active,
-                             int &light_id, f4 &isec, int *stack, BvhCounters &cnt) {
+                             int &light_id, f4 &isec, const BvhScratch &ws, BvhCounters &cnt) {
     const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
     if (lbv.enabled) {
-        light_id = closest_hit_bvh(sc, lbv, ray, active, 0, lights, current, 0.0f, stack, isec, cnt);
+        BvhScratch lws = ws;
+        lws.n_top = 0;
+        light_id = closest_hit_bvh(sc, lbv, ray, active, 0, lights, current, 0.0f, lws, isec, cnt);
     } else {
         isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
         light_id = closest_hit_range(sc.geo, 0, lights, ray, active, current, isec, -1);
     }
-    const bool blocked = (lights < count) && closer_any_hit_bvh(sc, bv, ray, isec, current, active, stack, cnt);
+    const bool blocked = (lights < count) && closer_any_hit_bvh(sc, bv, ray, isec, current, active, ws, cnt);
     if (blocked) return 0;
     return light_id < 0 ? 1 : 2;
 }
 
-// rt_closest_hit_batch through the hierarchy.
+// rt_closest_hit_batch through the hierarchy.  A fixed grid of single-wave workgroups strides over the
+// batch in chunks of 64 rays, so that each wave adds its counters to the shared totals once.
 __global__ __launch_bounds__(64) void k_closest_hit_batch_bvh(DScene sc, DBvh bv, const float *__restrict__ o,
                                                               const float *__restrict__ d, unsigned long long n,
                                                               int *__restrict__ id, float *__restrict__ uvt,
                                                               DStats *__restrict__ stats) {
     __shared__ int stack_mem[BVH_STACK * 64];
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    const unsigned long long j = live ? i : 0ull;
-    Ray ray;
-    ray.o = mk3(o[j * 3 + 0], o[j * 3 + 1], o[j * 3 + 2]);
-    ray.d = mk3(d[j * 3 + 0], d[j * 3 + 1], d[j * 3 + 2]);
-    f4 isec;
+    __shared__ v4f top_mem[64 * 4];               // single-wave workgroups: a small top only
+    BvhScratch ws;
+    ws.stack = stack_mem + threadIdx.x;
+    ws.top = (lds_v4f_ptr)top_mem;
+    ws.n_top = bv.enabled ? (bv.n_nodes < 64 ? bv.n_nodes : 64) : 0;
+    for (int i = threadIdx.x; i < ws.n_top * 4; i += 64) top_mem[i] = ((const v4f *)bv.nodes)[i];
+    __syncthreads();
     BvhCounters cnt;
     cnt.nodes = 0; cnt.tris = 0;
-    const int hit = closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, stack_mem + threadIdx.x, isec, cnt);
-    if (live) {
-        const float inv_det = 1.0f / isec.w;
-        id[i] = hit;
-        uvt[i * 3 + 0] = isec.x * inv_det;
-        uvt[i * 3 + 1] = isec.y * inv_det;
-        uvt[i * 3 + 2] = isec.z * inv_det;
+    const unsigned long long chunks = (n + 63ull) / 64ull;
+    for (unsigned long long c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const unsigned long long i = c * 64ull + threadIdx.x;
+        const bool live = i < n;
+        const unsigned long long j = live ? i : 0ull;
+        Ray ray;
+        ray.o = mk3(o[j * 3 + 0], o[j * 3 + 1], o[j * 3 + 2]);
+        ray.d = mk3(d[j * 3 + 0], d[j * 3 + 1], d[j * 3 + 2]);
+        f4 isec;
+        const int hit = closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, isec, cnt);
+        if (live) {
+            const float inv_det = 1.0f / isec.w;
+            id[i] = hit;
+            uvt[i * 3 + 0] = isec.x * inv_det;
+            uvt[i * 3 + 1] = isec.y * inv_det;
+            uvt[i * 3 + 2] = isec.z * inv_det;
+        }
     }
     const unsigned long long nn = wave_sum_u32(cnt.nodes), nt = wave_sum_u32(cnt.tris);
-    if ((threadIdx.x & 63) == 0 && (nn | nt)) { atomicAdd(&stats->ext_nodes, nn); atomicAdd(&stats->ext_tris, nt); }
+    if (threadIdx.x == 0 && (nn | nt)) { atomicAdd(&stats->ext_nodes, nn); atomicAdd(&stats->ext_tris, nt); }
 }
 
 }  // namespace rt

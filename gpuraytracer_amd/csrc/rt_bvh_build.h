@@ -217,11 +217,45 @@ inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool f
     }
 }
 
-constexpr int BVH_STACK_DEPTH = 32;
+#ifndef RT_BVH_STACK
+#define RT_BVH_STACK 32
+#endif
+constexpr int BVH_STACK_DEPTH = RT_BVH_STACK;   // entries of the traversal stack (rt_bvh.h)
+
+// Renumbers the inner nodes breadth first, so that the nodes nearest the root (the ones every ray visits)
+// are the first ones of the array: the kernels keep that prefix in LDS.
+inline void reorder_breadth_first(HostBvh &b) {
+    const size_t n = b.nodes.size() / 16;
+    if (n < 2) return;
+    std::vector<int32_t> order, new_index(n, -1);
+    order.reserve(n);
+    order.push_back(0);
+    for (size_t head = 0; head < order.size(); head++) {
+        const float *nd = &b.nodes[(size_t)order[head] * 16];
+        for (int c = 0; c < 2; c++) {
+            int32_t child;
+            memcpy(&child, &nd[12 + c], 4);
+            if (child >= 0) order.push_back(child);
+        }
+    }
+    for (size_t i = 0; i < order.size(); i++) new_index[order[i]] = (int32_t)i;
+    std::vector<float> nodes(b.nodes.size());
+    for (size_t i = 0; i < order.size(); i++) {
+        float *dst = &nodes[i * 16];
+        memcpy(dst, &b.nodes[(size_t)order[i] * 16], 64);
+        for (int c = 0; c < 2; c++) {
+            int32_t child;
+            memcpy(&child, &dst[12 + c], 4);
+            if (child >= 0) { child = new_index[child]; memcpy(&dst[12 + c], &child, 4); }
+        }
+    }
+    b.nodes.swap(nodes);
+}
 
 inline void build_bvh(const rt_triangle_model *tris, uint32_t count, HostBvh &out) {
     build_bvh_impl(tris, count, false, out);
     if (out.depth >= BVH_STACK_DEPTH - 2) build_bvh_impl(tris, count, true, out);
+    reorder_breadth_first(out);
 }
 
 }  // namespace rt

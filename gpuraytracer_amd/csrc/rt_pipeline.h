@@ -38,9 +38,20 @@
 
 namespace rt {
 
-constexpr int PIPE_WAVES = 256 * 16;    // persistent grid: 16 single-wave workgroups per CU, all resident
+#ifndef RT_WAVES_PER_CU
+#define RT_WAVES_PER_CU 16
+#endif
+#ifndef RT_WG_WAVES
+#define RT_WG_WAVES 8
+#endif
+constexpr int PIPE_WAVES = 256 * RT_WAVES_PER_CU;    // persistent grid, all waves resident
+constexpr int WG_WAVES = RT_WG_WAVES;                // waves per workgroup: they share the LDS copy of the hierarchy's top
+static_assert(PIPE_WAVES % WG_WAVES == 0, "the grid is a whole number of workgroups");
 
-// Queues without atomics.  Every pipeline kernel runs exactly PIPE_WAVES single-wave workgroups, and
+RT_DEV uint32_t wave_index() { return blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6); }
+RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
+
+// Queues without atomics.  Every pipeline kernel runs exactly PIPE_WAVES waves (in workgroups of WG_WAVES), and
 // wave v owns region v of every queue: it is the only one that appends to it (keeping the fill count
 // in a scalar register and storing it once at the end) and the only one that later consumes it.  A
 // wave can never emit more entries than it consumed, so a region of ceil(chunks / PIPE_WAVES) * 64
@@ -84,7 +95,7 @@ RT_DEV void region_push(uint32_t *__restrict__ region, uint32_t &fill, bool pred
 }
 
 RT_DEV void wstat_add(const PipeBuffers &b, int which, unsigned long long v) {
-    if (threadIdx.x == 0 && v) b.wstats[(size_t)blockIdx.x * 8 + which] += v;
+    if (lane_index() == 0 && v) b.wstats[(size_t)wave_index() * 8 + which] += v;
 }
 
 struct RouteFill { uint32_t shadow, glossy, next; };
@@ -126,17 +137,18 @@ RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffer
         store_path(b, id, ps);
     }
     to_next = to_next && (depth + 1 < max_depth);
-    const size_t region = (size_t)blockIdx.x * b.region_cap;
+    const size_t region = (size_t)wave_index() * b.region_cap;
     region_push(b.q_shadow + region, fill.shadow, to_shadow, id);
     region_push(b.q_glossy + region, fill.glossy, to_glossy, id);
     region_push(b.q_ext[q_in ^ 1] + region, fill.next, to_next, id);
 }
 
 RT_DEV void store_route_fill(const PipeBuffers &b, int q_in, const RouteFill &fill) {
-    if (threadIdx.x == 0) {
-        b.n_shadow[blockIdx.x] = fill.shadow;
-        b.n_glossy[blockIdx.x] = fill.glossy;
-        b.n_ext[q_in ^ 1][blockIdx.x] = fill.next;
+    if (lane_index() == 0) {
+        const uint32_t wave = wave_index();
+        b.n_shadow[wave] = fill.shadow;
+        b.n_glossy[wave] = fill.glossy;
+        b.n_ext[q_in ^ 1][wave] = fill.next;
     }
 }
 
@@ -145,16 +157,20 @@ RT_DEV void store_route_fill(const PipeBuffers &b, int q_in, const RouteFill &fi
 // shade its paths; otherwise it writes the hit record h0 = (u, v, t, triangle id; -1 = miss) and
 // k_shade does the shading.  BVH: hierarchy traversal instead of the loop over all triangles.
 template <bool FIRST, bool FUSED, bool BVH>
-__global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
-                                               const uint32_t *__restrict__ samples,
-                                               const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
-                                               uint32_t n_slots, int max_depth) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][blockIdx.x];
-    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)blockIdx.x * b.region_cap;
+__global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
+                                                          const uint32_t *__restrict__ samples,
+                                                          const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
+                                                          uint32_t n_slots, int max_depth) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][wave];
+    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)wave * b.region_cap;
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
-    __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
-    int *stack = stack_mem + lane;
+    __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
+    __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
+    BvhScratch ws;
+    ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
+    ws.top = (lds_v4f_ptr)top_mem;
+    ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     uint32_t n_paths = 0, n_rays = 0;
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, Pi
     fill.shadow = fill.glossy = fill.next = 0;
 
     // FIRST: chunks blockIdx, blockIdx + PIPE_WAVES, ... of the identity queue; else this wave's region
-    for (uint32_t base = FIRST ? blockIdx.x * 64u : 0u; base < total; base += FIRST ? gridDim.x * 64u : 64u) {
+    for (uint32_t base = FIRST ? wave * 64u : 0u; base < total; base += FIRST ? (uint32_t)PIPE_WAVES * 64u : 64u) {
         const uint32_t qi = base + lane;
         bool live = qi < total;
         uint32_t id = 0, kept_flags = 0;
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, Pi
         n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
-        const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, stack, isec, bc)
+        const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, isec, bc)
                             : closest_hit_bf(sc, ray, isec);
         const float inv_det = 1.0f / isec.w;
         if (FUSED) {
@@ -220,18 +236,18 @@ __global__ __launch_bounds__(64) void k_extend(DScene sc, DBvh bv, DFrame fr, Pi
 
 // Shade stage of the unfused form.
 template <bool FIRST>
-__global__ __launch_bounds__(64) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
-                                              const uint32_t *__restrict__ samples,
-                                              const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
-                                              uint32_t n_slots, int max_depth) {
-    const uint32_t lane = threadIdx.x;
-    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][blockIdx.x];
-    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)blockIdx.x * b.region_cap;
+__global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
+                                                         const uint32_t *__restrict__ samples,
+                                                         const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
+                                                         uint32_t n_slots, int max_depth) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][wave];
+    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)wave * b.region_cap;
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
 
-    for (uint32_t base = FIRST ? blockIdx.x * 64u : 0u; base < total; base += FIRST ? gridDim.x * 64u : 64u) {
+    for (uint32_t base = FIRST ? wave * 64u : 0u; base < total; base += FIRST ? (uint32_t)PIPE_WAVES * 64u : 64u) {
         const uint32_t qi = base + lane;
         bool live = qi < total;
         uint32_t id = 0, kept_flags = 0;
@@ -265,15 +281,20 @@ __global__ __launch_bounds__(64) void k_shade(DScene sc, DFrame fr, PipeBuffers 
 
 // Shadow-probe stage: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579.
 template <bool BVH>
-__global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in, int max_depth) {
-    const uint32_t lane = threadIdx.x;
-    __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
-    int *stack = stack_mem + lane;
+__global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in,
+                                                                int max_depth) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
+    __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
+    BvhScratch ws;
+    ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
+    ws.top = (lds_v4f_ptr)top_mem;
+    ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
-    const size_t region = (size_t)blockIdx.x * b.region_cap;
-    const uint32_t total = b.n_shadow[blockIdx.x];
-    uint32_t fill_next = b.n_ext[q_in ^ 1][blockIdx.x];
+    const size_t region = (size_t)wave * b.region_cap;
+    const uint32_t total = b.n_shadow[wave];
+    uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
     for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t qi = base + lane;
         const bool live = qi < total;
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuf
         probe.d = mk3(pr.x, pr.y, pr.z);
         const int current = (int)(sc3.y & CURRENT_MASK);
         uint32_t kept_flags = sc3.y >> 30;
-        const bool blocked = BVH ? shadow_any_hit_bvh(sc, bv, probe, pr.w, current, live, stack, bc)
+        const bool blocked = BVH ? shadow_any_hit_bvh(sc, bv, probe, pr.w, current, live, ws, bc)
                                  : shadow_any_hit_bf(sc, probe, pr.w, current, live);
         bool to_next = false;
         if (live) {
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuf
         to_next = to_next && (depth + 1 < max_depth);
         region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next, id);
     }
-    if (lane == 0) b.n_ext[q_in ^ 1][blockIdx.x] = fill_next;
+    if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
     wstat_add(b, WSTAT_SHADOW, total);
     if (BVH) {
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
@@ -317,16 +338,20 @@ __global__ __launch_bounds__(64) void k_probe_shadow(DScene sc, DBvh bv, PipeBuf
 
 // Glossy-probe stage: search of sampleLightGlossy (raytracer.glsl:403-437), then :557-579.
 template <bool BVH>
-__global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth,
-                                                     int q_in, int max_depth) {
-    const uint32_t lane = threadIdx.x;
-    __shared__ int stack_mem[BVH ? BVH_STACK * 64 : 64];
-    int *stack = stack_mem + lane;
+__global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
+                                                                int depth, int q_in, int max_depth) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
+    __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
+    BvhScratch ws;
+    ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
+    ws.top = (lds_v4f_ptr)top_mem;
+    ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
-    const size_t region = (size_t)blockIdx.x * b.region_cap;
-    const uint32_t total = b.n_glossy[blockIdx.x];
-    uint32_t fill_next = b.n_ext[q_in ^ 1][blockIdx.x];
+    const size_t region = (size_t)wave * b.region_cap;
+    const uint32_t total = b.n_glossy[wave];
+    uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
     for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t qi = base + lane;
         const bool live = qi < total;
@@ -340,7 +365,7 @@ __global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DBvh bv, DBvh lb
         f4 lsec;
         const int current = (int)(sc3.y & CURRENT_MASK);
         uint32_t kept_flags = sc3.y >> 30;
-        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, probe, current, live, light_id, lsec, stack, bc)
+        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, probe, current, live, light_id, lsec, ws, bc)
                                 : glossy_search_bf(sc, probe, current, live, light_id, lsec);
         bool to_next = false;
         if (live) {
@@ -361,7 +386,7 @@ __global__ __launch_bounds__(64) void k_probe_glossy(DScene sc, DBvh bv, DBvh lb
         to_next = to_next && (depth + 1 < max_depth);
         region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next, id);
     }
-    if (lane == 0) b.n_ext[q_in ^ 1][blockIdx.x] = fill_next;
+    if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
     wstat_add(b, WSTAT_GLOSSY, total);
     if (BVH) {
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
@@ -579,7 +604,7 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         return hipEventRecord(events[ev_used++], stream);
     };
 
-    const dim3 grid(PIPE_WAVES), block(64);
+    const dim3 grid(PIPE_WAVES / WG_WAVES), block(64 * WG_WAVES);
     int q_in = 0;
     for (int depth = 0; depth < max_depth; depth++) {
         PIPE_TRY(stamp(depth == 0 ? 3 : 0));
