@@ -14,6 +14,10 @@ With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank rend
 of samples per pixel with SAMPLE = rank + N*k (weak scaling), the scene is replicated, and the
 per-GPU radiance sums are added onto rank 0 by one RCCL reduce inside the timed region.
 
+Other workloads (not the headline; `--workload`): `obiwan` = the bundled 12 030-triangle model at RECURSION 16,
+`c3` = a synthetic 1 M-triangle textured height field (gpuraytracer_amd/synthetic.py) ingested through the
+OBJ/MTL reader.
+
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -28,7 +32,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-RECURSION = 6
 # FP32 vector rate without fused multiply-add: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (one flop per lane
 # and issue slot); half of the 157.3 TFLOP/s FMA figure.  The intersection arithmetic may not contract.
 PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
@@ -42,10 +45,11 @@ def constant_env():
     return env
 
 
-def cpu_baseline(scene, cam, clock, budget_s=12.0):
+def cpu_baseline(scene, cam, clock, recursion, budget_s=12.0):
     """The CPU restatement (oracle/, C-library math, OpenMP) on a bounded sample of the same workload:
     whole 1080p frames of consecutive SAMPLE indices, as many as fit the time budget."""
     from oracle import oracle
+    RECURSION = recursion
     sc = oracle.OracleScene(*scene, libm=True)
     sc.upload_env(constant_env())
     t0 = time.perf_counter()
@@ -60,6 +64,37 @@ def cpu_baseline(scene, cam, clock, budget_s=12.0):
             "sample": "%dx%d, SAMPLE 0..%d (%d rays) in %.2f s, OpenMP over pixels" % (W, H, spp - 1, st["rays"], dt)}
 
 
+def load_workload(g, args):
+    """Returns (scene tuple, camera, recursion, description, texture uploads or None)."""
+    if args.workload == "cubes":
+        scene = g.read_rtscene(os.path.join(ROOT, "tests", "golden", "scenes", "cubes.rtscene"))
+        return scene, g.camera_matrix(), 6, "cubes 424 tris", None
+    if args.workload == "obiwan":
+        scene = g.read_rtscene(os.path.join(ROOT, "tests", "golden", "scenes", "_ObiWan.rtscene"))
+        return scene, g.camera_matrix(), 16, "_ObiWan 12030 tris", None
+    import tempfile
+    from gpuraytracer_amd import host, synthetic
+    with tempfile.TemporaryDirectory() as tmp:
+        base = os.path.join(tmp, "grid")
+        synthetic.write_displaced_grid(base, args.grid)
+        scene = host.load_wavefront(base)
+    cam = g.camera_matrix((0.0, 2.2, -5.5), (-0.45, 0.0))
+    layers = synthetic.texture_layers(args.atlas)
+    return scene, cam, 6, "synthetic height field %d tris, %d^2 atlas on 2 materials" % (len(scene[0]), args.atlas), layers
+
+
+def measured_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter pass of this command
+    (FETCH_SIZE and WRITE_SIZE, separate runs; FETCH_SIZE doubled as gfx950 reports half of wide reads)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)[kernel_key]
+        return 2.0 * t["FETCH_SIZE_KB"] * 1024.0 + t["WRITE_SIZE_KB"] * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +105,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1)
     ap.add_argument("--fuse-shade", type=int, default=1)
     ap.add_argument("--accel", type=int, default=-1, help="-1 auto, 0 loops over all triangles, 1 hierarchy")
+    ap.add_argument("--workload", choices=("cubes", "obiwan", "c3"), default="cubes")
+    ap.add_argument("--grid", type=int, default=724, help="c3: cells per side of the height field")
+    ap.add_argument("--atlas", type=int, default=1024, help="c3: edge of the texture layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
@@ -91,8 +129,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    scene = g.read_rtscene(os.path.join(ROOT, "tests", "golden", "scenes", "cubes.rtscene"))
-    cam = g.camera_matrix()
+    scene, cam, RECURSION, workload_name, layers = load_workload(g, args)
     clock = g.DEFAULT_CLOCK
 
     ctx = g.Context(local_rank)
@@ -103,7 +140,17 @@ def main():
     ctx.set_option("profiling", 1)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    t_up = time.perf_counter()
     ctx.upload_scene(*scene)
+    upload_s = time.perf_counter() - t_up      # includes building the hierarchy on the host
+    if layers is not None:
+        ctx.set_atlas_size(args.atlas)
+        flags = np.zeros(len(scene[3]), dtype=np.int32)
+        for m in (0, 1):
+            for k in range(3):
+                ctx.upload_atlas_layer(m, k, layers[k])
+            flags[m] = 1
+        ctx.set_has_texture(flags)
     ctx.upload_env(constant_env())
     ctx.resize(W, H)
     sums = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")     # accumulation buffer (float4 per pixel)
@@ -165,8 +212,9 @@ def main():
             achieved = algo / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": "k_extend<FIRST,FUSED,BVH> (depth-0 closest hit by hierarchy + shading)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": None, "bytes_per_launch": algo / ext_n,
-                    "note": "latency/issue bound: 10 node visits + 6 triangle tests per ray, see profiles/"}
+                    "traffic": measured_traffic("k_extend<true, true, true>") if args.workload == "cubes" else None,
+                    "bytes_per_launch": algo / ext_n,
+                    "note": "instruction-issue bound (SIMDs ~80 % busy), not bandwidth bound: see profiles/"}
         else:
             flops = float(st["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
             achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
@@ -187,8 +235,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cubes 424 tris, 1920x1080, RECURSION 6, %d spp per GPU (%d spp/step), "
-                                   "constant environment" % (args.steps * spp, spp),
+            "config": {"workload": "%s, 1920x1080, RECURSION %d, %d spp per GPU (%d spp/step), "
+                                   "constant environment" % (workload_name, RECURSION, args.steps * spp, spp),
                        "pipeline": "staged" if args.pipeline else "single-kernel",
                        "closest_hit": "hierarchy (exact)" if used_bvh else "loop over all triangles",
                        "parallelism": "spp split x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
@@ -198,9 +246,10 @@ def main():
             "mean_radiance": mean,
             "nonfinite_pixels": nonfinite_pixels,
             "bvh": {k: st[k] for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris")},
+            "scene_upload_s": upload_s,
             "roofline": roof,
         }
-        if world == 1 and used_bvh and not args.no_bruteforce_pass:
+        if world == 1 and used_bvh and not args.no_bruteforce_pass and args.workload == "cubes":
             # the reference's own algorithm (loop over all COUNT triangles per query) on the same GPU, short pass
             ctx.set_option("accel", 0)
             ctx.set_option("batch_samples", 4)
@@ -221,7 +270,7 @@ def main():
                 "flops_per_launch": f1 / max(1, s1["extend0_launches"]),
                 "value_Mrays_per_s": s1["rays"] / dt1 / 1e6, "sample": "64 spp"}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, cam, clock)
+            out["cpu_baseline"] = cpu_baseline(scene, cam, clock, RECURSION)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

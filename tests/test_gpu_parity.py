@@ -306,3 +306,34 @@ def test_error_behaviour(oracle_mod, cubes):
         assert n == 1 and np.isfinite(img).all()
     finally:
         ctx.close()
+
+
+def test_synthetic_height_field_textured(gpu_ctx, oracle_mod, tmp_path):
+    # the C3-style workload at small size: OBJ/MTL ingest -> hierarchy -> textured shading; hierarchy, loop form
+    # and the checker agree bit for bit
+    from gpuraytracer_amd import host, synthetic
+    base = str(tmp_path / "grid")
+    n_tris = synthetic.write_displaced_grid(base, 40)
+    scene = host.load_wavefront(base)
+    assert len(scene[0]) == n_tris and scene[2] == 4
+    layers = synthetic.texture_layers(64)
+    flags = np.array([1, 1, 0], np.int32)
+    cam = camera_matrix((0.0, 2.2, -5.5), (-0.45, 0.0))
+    gpu_ctx.upload_scene(*scene)
+    gpu_ctx.upload_env(gradient_env())
+    gpu_ctx.set_atlas_size(64)
+    sc = oracle_mod.OracleScene(*scene)
+    sc.upload_env(gradient_env())
+    sc.set_atlas_size(64)
+    for target in (gpu_ctx, sc):
+        for m in (0, 1):
+            for k in range(3):
+                target.upload_atlas_layer(m, k, layers[k])
+        target.set_has_texture(flags)
+    want, wst = sc.render(cam, 777, 6, 1.0, 64, 40, 0, 2)
+    for pipeline in (1, 3):
+        img, st = _render(gpu_ctx, 64, 40, 0, 2, clock=777, pipeline=pipeline, cam=cam)
+        assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
+        assert st["rays"] == wst["rays"] and st["shadow_probes"] == wst["shadow_probes"]
+    assert wst["rays"] > 1.05 * wst["pixel_samples"] and wst["shadow_probes"] > 0     # the camera sees the surface
+    gpu_ctx.set_atlas_size(4096)
