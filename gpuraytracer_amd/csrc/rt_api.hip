@@ -61,6 +61,7 @@ struct rt_context {
     int batch_samples = 16;
     int profiling = 0;
     int fuse_shade = 1;
+    int refill = 0;
 
     // stats
     DStats *d_stats = nullptr;
@@ -528,7 +529,7 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
             const bool acc = use_accel(ctx);
             hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame,
                                          ctx->d_sum, ctx->d_samples, (int)n, ctx->stream, ctx->profiling != 0,
-                                         ctx->fuse_shade != 0, &ctx->host_stats, &msg);
+                                         ctx->fuse_shade != 0, ctx->refill != 0, &ctx->host_stats, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
                             msg ? msg : "pipeline", hipGetErrorString(e));
@@ -699,6 +700,8 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
         ctx->accel = (int)value;
     } else if (!strcmp(name, "fuse_shade")) {
         ctx->fuse_shade = value ? 1 : 0;
+    } else if (!strcmp(name, "refill")) {
+        ctx->refill = value ? 1 : 0;
     } else if (!strcmp(name, "profiling")) {
         ctx->profiling = value ? 1 : 0;
     } else {

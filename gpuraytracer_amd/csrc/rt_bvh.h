@@ -109,19 +109,30 @@ RT_DEV float box_entry(const BvhRay &br, f3 lo, f3 hi, float t_max) {
 
 struct BvhCounters { uint32_t nodes, tris; };
 
-// Generic traversal.  `leaf(slot)` is called for every triangle slot of every leaf whose box the ray
-// enters within t_limit(); it returns false to stop the whole traversal (any-hit found).
+// Traversal state of one lane; it survives between calls of bvh_advance, so that a wave can hand finished
+// lanes new rays while the others are still under way.
+struct TravState {
+    int node, sp;
+    bool run;
+};
+
+// Advances every running lane of the wave.  `leaf(slot)` is called for every triangle slot of every leaf whose
+// box the ray enters within t_limit(); it returns false to stop that lane's traversal (any-hit found).
+// Returns when no lane runs any more, or as soon as at least `stop_at` lanes of the wave are not running
+// (pass 65 to run to the end).
+// "while-while" order: all lanes first descend through inner nodes until each holds a leaf (or has finished),
+// then all leaves are processed together; this keeps box tests and triangle tests of a wave from
+// interleaving lane by lane.
 template <typename LeafFn, typename LimitFn>
-RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const BvhScratch &ws, LeafFn leaf, LimitFn t_limit,
-                         BvhCounters &cnt) {
+RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const BvhScratch &ws, TravState &ts, int stop_at, LeafFn leaf,
+                        LimitFn t_limit, BvhCounters &cnt) {
     int *stack = ws.stack;
-    int sp = 0;
-    int node = 0;
-    bool run = active;
-    // "while-while" order: all lanes first descend through inner nodes until each holds a leaf (or has
-    // finished), then all leaves are processed together; this keeps box tests and triangle tests of a
-    // wave from interleaving lane by lane.
-    while (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+    int sp = ts.sp;
+    int node = ts.node;
+    bool run = ts.run;
+    for (;;) {
+        const unsigned long long running = __builtin_amdgcn_ballot_w64(run);
+        if (running == 0ull || 64 - (int)__popcll(running) >= stop_at) break;
         while (__builtin_amdgcn_ballot_w64(run && node >= 0) != 0ull) {
             if (run && node >= 0) {
                 v4f q0, q1, q2, q3;
@@ -151,7 +162,7 @@ RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const Bv
                 node = next;
             }
         }
-        if (run && node < 0) {      // a leaf
+        if (run) {      // node < 0: a leaf
             const int code = ~node;
             const int first = code >> 3, n = code & 7;
             bool go_on = true;
@@ -167,6 +178,18 @@ RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const Bv
             }
         }
     }
+    ts.sp = sp;
+    ts.node = node;
+    ts.run = run;
+}
+
+// One traversal from the root to the end for the lanes with `active`.
+template <typename LeafFn, typename LimitFn>
+RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const BvhScratch &ws, LeafFn leaf, LimitFn t_limit,
+                         BvhCounters &cnt) {
+    TravState ts;
+    ts.node = 0; ts.sp = 0; ts.run = active;
+    bvh_advance(bv, br, ws, ts, 65, leaf, t_limit, cnt);
 }
 
 // The triangle record of a leaf slot (3 of the 4 float4 of the slot).  Its index is the first word of the
@@ -183,6 +206,56 @@ RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot) {
     return t;
 }
 
+// Running state of a closest-hit query: the fold of the header comment.
+struct ClosestFold {
+    int best;
+    float t_min;
+    int n_near;
+    f4 st;       // (x, y, rd, det) of the running best, or (0, 0, -1, w_init)
+};
+RT_DEV void closest_fold_reset(ClosestFold &cf, float w_init) {
+    cf.best = -1;
+    cf.t_min = __builtin_inff();
+    cf.n_near = 0;
+    cf.st.x = 0.0f; cf.st.y = 0.0f; cf.st.z = -1.0f; cf.st.w = w_init;
+}
+// Tests the triangle of leaf slot `slot` and folds it in if it is a candidate.  Triangles outside
+// [begin_id, end_id) and `current` are skipped.
+RT_DEV void closest_fold_leaf(const DBvh &bv, const Ray &ray, int slot, int begin_id, int end_id, int current, ClosestFold &cf) {
+    const Tri t = load_leaf_tri(bv, slot);
+    const float det = -dot(ray.d, t.n);
+    const f3 delta = ray.o - t.p;
+    const float rd = dot(t.n, delta);
+    if ((det <= 0.0f) | (rd <= 0.0f)) return;
+    PlaneTest pt;
+    pt.det = det; pt.rd = rd; pt.delta = delta;
+    float rx, ry;
+    if (!inside_test(ray, t, pt, rx, ry)) return;
+    const int id = leaf_tri_id(bv, slot);
+    if (id < begin_id || id >= end_id || id == current) return;
+    // a candidate: rule 3 between it and the running best
+    bool take;
+    if (cf.best < 0) take = true;
+    else if (id > cf.best) take = !(rd * cf.st.w > cf.st.z * det);
+    else take = (cf.st.z * det > rd * cf.st.w);
+    const float tc = rd * __builtin_amdgcn_rcpf(det);     // pruning only: 1 ulp is far inside the margin
+    if (tc * BVH_NEAR < cf.t_min) cf.n_near = 1;
+    else if (tc <= cf.t_min * BVH_NEAR) cf.n_near++;
+    cf.t_min = __builtin_fminf(cf.t_min, tc);
+    if (take) { cf.best = id; cf.st.x = rx; cf.st.y = ry; cf.st.z = rd; cf.st.w = det; }
+}
+// Rare cases, redone by the index-order loop: three or more candidates within the margin of the closest
+// depth, or a non-finite ray.  Wave-collective; `redo` selects the lanes.
+RT_DEV void closest_fold_redo(const DScene &sc, const Ray &ray, bool redo, int begin_id, int end_id, int current, float w_init,
+                              ClosestFold &cf) {
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+        f4 s2;
+        s2.x = 0.0f; s2.y = 0.0f; s2.z = -1.0f; s2.w = w_init;
+        const int b2 = closest_hit_range(sc.geo, begin_id, end_id, ray, redo, current, s2, -1);
+        if (redo) { cf.best = b2; cf.st = s2; }
+    }
+}
+
 // Closest hit with the reference's fold semantics (see the header comment).  `begin_id`..`end_id`
 // restricts the triangles considered (the glossy probe folds over the light triangles only),
 // `current` is skipped.  Returns the triangle id or -1; isec = (x, y, rd, det) of the winner, or
@@ -190,49 +263,14 @@ RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot) {
 RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, int begin_id, int end_id,
                            int current, float w_init, const BvhScratch &ws, f4 &isec, BvhCounters &cnt) {
     const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
-    int best = -1;
-    float t_min = __builtin_inff();
-    int n_near = 0;
-    f4 st;
-    st.x = 0.0f; st.y = 0.0f; st.z = -1.0f; st.w = w_init;
-    auto leaf = [&](int slot) -> bool {
-        const Tri t = load_leaf_tri(bv, slot);
-        const float det = -dot(ray.d, t.n);
-        const f3 delta = ray.o - t.p;
-        const float rd = dot(t.n, delta);
-        if ((det <= 0.0f) | (rd <= 0.0f)) return true;
-        PlaneTest pt;
-        pt.det = det; pt.rd = rd; pt.delta = delta;
-        float rx, ry;
-        if (!inside_test(ray, t, pt, rx, ry)) return true;
-        const int id = leaf_tri_id(bv, slot);
-        if (id < begin_id || id >= end_id || id == current) return true;
-        // a candidate: rule 3 between it and the running best
-        bool take;
-        if (best < 0) take = true;
-        else if (id > best) take = !(rd * st.w > st.z * det);
-        else take = (st.z * det > rd * st.w);
-        const float tc = rd * __builtin_amdgcn_rcpf(det);     // pruning only: 1 ulp is far inside the margin
-        if (tc * BVH_NEAR < t_min) n_near = 1;
-        else if (tc <= t_min * BVH_NEAR) n_near++;
-        t_min = __builtin_fminf(t_min, tc);
-        if (take) { best = id; st.x = rx; st.y = ry; st.z = rd; st.w = det; }
-        return true;
-    };
-    auto limit = [&]() -> float { return t_min * BVH_NEAR; };
+    ClosestFold cf;
+    closest_fold_reset(cf, w_init);
+    auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ray, slot, begin_id, end_id, current, cf); return true; };
+    auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
     bvh_traverse(bv, br, active && br.finite, ws, leaf, limit, cnt);
-
-    // Rare cases, redone by the index-order loop: three or more candidates within the margin of the
-    // closest depth, or a non-finite ray.
-    const bool redo = active && (!br.finite || n_near > 2);
-    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-        f4 s2;
-        s2.x = 0.0f; s2.y = 0.0f; s2.z = -1.0f; s2.w = w_init;
-        const int b2 = closest_hit_range(sc.geo, begin_id, end_id, ray, redo, current, s2, -1);
-        if (redo) { best = b2; st = s2; }
-    }
-    isec = st;
-    return best;
+    closest_fold_redo(sc, ray, active && (!br.finite || cf.n_near > 2), begin_id, end_id, current, w_init, cf);
+    isec = cf.st;
+    return cf.best;
 }
 
 // sampleLight's occlusion query (raytracer.glsl:372-378): is any triangle != current hit by

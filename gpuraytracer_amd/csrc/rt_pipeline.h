@@ -394,6 +394,316 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Traversal stages with lane refill.  Rays that start on surfaces are incoherent: in a wave that takes 64
+// queue entries and waits for the slowest, under a third of the lanes do useful work in the node loop.
+// Here a wave keeps its lanes busy instead: as soon as REFILL_MIN lanes have finished their ray, their
+// results are retired and the free lanes fetch the next entries of the wave's queue region while the other
+// lanes carry on where they were (bvh_advance keeps per-lane traversal state).  What is retired with a
+// partly filled wave is only the short rest of the bounce (or a 16-byte hit record), so the loss there is
+// small.  A path's arithmetic does not depend on which lane or in which order it is processed, and the
+// order of a queue region only decides the order of the next region, so results stay bit-identical.
+constexpr int REFILL_MIN = 24;
+
+// Hands queue entries to the lanes that are not busy, once at least REFILL_MIN lanes are free.  Returns
+// true for the lanes that received an entry (in `id`).
+RT_DEV bool refill_take(const uint32_t *__restrict__ q, uint32_t total, uint32_t &next, bool busy, uint32_t &id) {
+    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+    const uint32_t n_idle = (uint32_t)__popcll(idle);
+    bool got = false;
+    if (next < total && n_idle >= (uint32_t)REFILL_MIN) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+        const uint32_t avail = total - next;
+        const uint32_t take = n_idle < avail ? n_idle : avail;
+        if (!busy && rank < take) { id = q[next + rank]; got = true; }
+        next += take;
+    }
+    return got;
+}
+
+// All light probes of one depth in one launch: the shadow queue, then the glossy queue in two passes
+// (closest light through the hierarchy over the emissive triangles; then the any-hit search over the
+// others, raytracer.glsl:403-419 in the two-phase form of glossy_search_bf).
+__global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth,
+                                                                int q_in, int max_depth) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    __shared__ int stack_mem[BVH_STACK * 64 * WG_WAVES];
+    __shared__ v4f top_mem[BVH_TOP_NODES * 4];
+    BvhScratch ws;
+    ws.stack = stack_mem + (threadIdx.x >> 6) * (BVH_STACK * 64) + lane;
+    ws.top = (lds_v4f_ptr)top_mem;
+    ws.n_top = bvh_stage_top(bv, top_mem);
+    BvhScratch lws = ws;
+    lws.n_top = 0;
+    BvhCounters bc;
+    bc.nodes = 0; bc.tris = 0;
+    const size_t region = (size_t)wave * b.region_cap;
+    uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
+    const bool deeper = depth + 1 < max_depth;
+    const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
+
+    // ---- shadow queue: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579
+    {
+        const uint32_t total = b.n_shadow[wave];
+        const uint32_t *__restrict__ q = b.q_shadow + region;
+        uint32_t next = 0, id = 0, seed = 0, kept_flags = 0;
+        bool busy = false, ok = true, blocked = false;
+        TravState ts;
+        ts.node = 0; ts.sp = 0; ts.run = false;
+        Ray probe;
+        probe.o = probe.d = mk3(0.0f, 0.0f, 0.0f);
+        float max_t = 0.0f;
+        int current = -1;
+        BvhRay br = bvh_ray_setup(probe, bv.max_abs_coord);
+        for (;;) {
+            uint32_t nid = 0;
+            if (refill_take(q, total, next, busy, nid)) {
+                id = nid;
+                const float4 a = b.s0[id], pr = b.p0[id];
+                const uint2 sc3 = b.s3[id];
+                probe.o = mk3(a.x, a.y, a.z);
+                probe.d = mk3(pr.x, pr.y, pr.z);
+                max_t = pr.w;
+                seed = sc3.x;
+                current = (int)(sc3.y & CURRENT_MASK);
+                kept_flags = sc3.y >> 30;
+                br = bvh_ray_setup(probe, bv.max_abs_coord);
+                ok = br.finite && ((max_t - max_t) == 0.0f);
+                blocked = false;
+                busy = true;
+                ts.node = 0; ts.sp = 0; ts.run = ok;
+            }
+            if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
+            auto leaf = [&](int slot) -> bool {
+                const Tri t = load_leaf_tri(bv, slot);
+                if (intersect_triangle_shadow(probe, t, max_t) && leaf_tri_id(bv, slot) != current) { blocked = true; return false; }
+                return true;
+            };
+            const float lim = max_t * BVH_NEAR;
+            auto limit = [&]() -> float { return lim; };
+            bvh_advance(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
+            const bool fin = busy && !ts.run;
+            const bool redo = fin && !ok;
+            if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+                const bool b2 = shadow_any_hit_bf(sc, probe, max_t, current, redo);
+                if (redo) blocked = b2;
+            }
+            bool to_next = false;
+            if (fin) {
+                PathState ps;
+                load_path(b, id, ps);
+                ps.seed = seed;
+                const float4 c = b.p1[id], al = b.p2[id];
+                ps.kept_diff = mk3(0.0f, 0.0f, 0.0f);
+                if (blocked) {
+                    if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
+                } else {
+                    b.kd[id] = make_float4(c.x, c.y, c.z, 0.0f);
+                    kept_flags |= KEPT_DIFF;
+                }
+                to_next = finish_diffuse(sc, ps, current, !blocked, mk3(c.x, c.y, c.z), mk3(al.x, al.y, al.z), c.w);
+                store_path(b, id, ps);
+                b.s3[id] = make_uint2(ps.seed, (uint32_t)current | (kept_flags << 30));
+            }
+            region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next && deeper, id);
+            busy = busy && ts.run;
+        }
+        wstat_add(b, WSTAT_SHADOW, total);
+    }
+
+    // ---- glossy queue, pass 1: closest emissive triangle -> p2 = its (x, y, rd, det), p0.w = its index
+    const uint32_t g_total = b.n_glossy[wave];
+    const uint32_t *__restrict__ gq = b.q_glossy + region;
+    if (lbv.enabled) {
+        uint32_t next = 0, id = 0;
+        bool busy = false;
+        TravState ts;
+        ts.node = 0; ts.sp = 0; ts.run = false;
+        Ray probe;
+        probe.o = probe.d = mk3(0.0f, 0.0f, 0.0f);
+        int current = -1;
+        BvhRay br = bvh_ray_setup(probe, lbv.max_abs_coord);
+        ClosestFold cf;
+        closest_fold_reset(cf, 0.0f);
+        for (;;) {
+            uint32_t nid = 0;
+            if (refill_take(gq, g_total, next, busy, nid)) {
+                id = nid;
+                const float4 a = b.s0[id], pr = b.p0[id];
+                probe.o = mk3(a.x, a.y, a.z);
+                probe.d = mk3(pr.x, pr.y, pr.z);
+                current = (int)(b.s3[id].y & CURRENT_MASK);
+                br = bvh_ray_setup(probe, lbv.max_abs_coord);
+                closest_fold_reset(cf, 0.0f);
+                busy = true;
+                ts.node = 0; ts.sp = 0; ts.run = br.finite;
+            }
+            if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
+            auto leaf = [&](int slot) -> bool { closest_fold_leaf(lbv, probe, slot, 0, lights, current, cf); return true; };
+            auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
+            bvh_advance(lbv, br, lws, ts, next < g_total ? REFILL_MIN : 65, leaf, limit, bc);
+            const bool fin = busy && !ts.run;
+            closest_fold_redo(sc, probe, fin && (!br.finite || cf.n_near > 2), 0, lights, current, 0.0f, cf);
+            if (fin) {
+                b.p2[id] = make_float4(cf.st.x, cf.st.y, cf.st.z, cf.st.w);
+                ((float *)&b.p0[id])[3] = __int_as_float(cf.best);
+            }
+            busy = busy && ts.run;
+        }
+    } else {
+        for (uint32_t base = 0; base < g_total; base += 64u) {
+            const bool live = base + lane < g_total;
+            const uint32_t id = live ? gq[base + lane] : 0u;
+            const float4 a = b.s0[id], pr = b.p0[id];
+            Ray probe;
+            probe.o = mk3(a.x, a.y, a.z);
+            probe.d = mk3(pr.x, pr.y, pr.z);
+            const int current = (int)(b.s3[id].y & CURRENT_MASK);
+            f4 isec;
+            isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
+            const int light_id = closest_hit_range(sc.geo, 0, lights, probe, live, current, isec, -1);
+            if (live) {
+                b.p2[id] = make_float4(isec.x, isec.y, isec.z, isec.w);
+                ((float *)&b.p0[id])[3] = __int_as_float(light_id);
+            }
+        }
+    }
+    // the records of pass 1 are read back by other lanes of this wave: make them visible
+    __threadfence();
+
+    // ---- glossy queue, pass 2: is any non-emissive triangle not farther than that light?  then :420-437, :557-579
+    {
+        uint32_t next = 0, id = 0, seed = 0, kept_flags = 0;
+        bool busy = false, ok = true, blocked = false;
+        TravState ts;
+        ts.node = 0; ts.sp = 0; ts.run = false;
+        Ray probe;
+        probe.o = probe.d = mk3(0.0f, 0.0f, 0.0f);
+        int current = -1, light_id = -1;
+        f4 isec;
+        isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
+        float lim = 0.0f;
+        BvhRay br = bvh_ray_setup(probe, bv.max_abs_coord);
+        for (;;) {
+            uint32_t nid = 0;
+            if (refill_take(gq, g_total, next, busy, nid)) {
+                id = nid;
+                const float4 a = b.s0[id], pr = b.p0[id], ls = b.p2[id];
+                const uint2 sc3 = b.s3[id];
+                probe.o = mk3(a.x, a.y, a.z);
+                probe.d = mk3(pr.x, pr.y, pr.z);
+                light_id = __float_as_int(pr.w);
+                isec.x = ls.x; isec.y = ls.y; isec.z = ls.z; isec.w = ls.w;
+                seed = sc3.x;
+                current = (int)(sc3.y & CURRENT_MASK);
+                kept_flags = sc3.y >> 30;
+                br = bvh_ray_setup(probe, bv.max_abs_coord);
+                const bool bounded = isec.z >= 0.0f;       // a light was hit: only triangles not farther than it matter
+                const float t_light = isec.z / isec.w;
+                ok = br.finite && (!bounded || (t_light - t_light) == 0.0f);
+                lim = bounded ? t_light * BVH_NEAR : __builtin_inff();
+                blocked = false;
+                busy = true;
+                ts.node = 0; ts.sp = 0; ts.run = ok && (lights < count);
+            }
+            if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
+            auto leaf = [&](int slot) -> bool {
+                const Tri t = load_leaf_tri(bv, slot);
+                PlaneTest pt;
+                float rx, ry;
+                if (plane_test_closest(probe, t, isec, pt) && inside_test(probe, t, pt, rx, ry)) {
+                    const int tid = leaf_tri_id(bv, slot);
+                    if (tid >= lights && tid != current) { blocked = true; return false; }
+                }
+                return true;
+            };
+            auto limit = [&]() -> float { return lim; };
+            bvh_advance(bv, br, ws, ts, next < g_total ? REFILL_MIN : 65, leaf, limit, bc);
+            const bool fin = busy && !ts.run;
+            const bool redo = fin && !ok && (lights < count);
+            if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+                const bool b2 = closer_any_hit_range(sc.geo, lights, count, probe, isec, current, redo);
+                if (redo) blocked = b2;
+            }
+            bool to_next = false;
+            if (fin) {
+                const int outcome = blocked ? 0 : (light_id < 0 ? 1 : 2);
+                PathState ps;
+                load_path(b, id, ps);
+                ps.seed = seed;
+                const float4 c = b.p1[id];
+                ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
+                if (outcome == 0 && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
+                to_next = finish_glossy(sc, fr, ps, current, outcome, probe.d, light_id, isec, mk3(c.x, c.y, c.z), c.w);
+                if (outcome != 0) {
+                    b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
+                    kept_flags |= KEPT_SPEC;
+                }
+                store_path(b, id, ps);
+                b.s3[id] = make_uint2(ps.seed, (uint32_t)current | (kept_flags << 30));
+            }
+            region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next && deeper, id);
+            busy = busy && ts.run;
+        }
+        wstat_add(b, WSTAT_GLOSSY, g_total);
+    }
+    if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
+    wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
+    wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(bc.tris));
+}
+
+// Extend stage for depth >= 1 with lane refill: the closest-hit search alone; it leaves the hit record
+// h0 = (u, v, t, triangle id; -1 = miss) and k_shade does the shading with full waves.
+__global__ __launch_bounds__(64 * WG_WAVES) void k_extend_refill(DScene sc, DBvh bv, PipeBuffers b, int q_in) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    __shared__ int stack_mem[BVH_STACK * 64 * WG_WAVES];
+    __shared__ v4f top_mem[BVH_TOP_NODES * 4];
+    BvhScratch ws;
+    ws.stack = stack_mem + (threadIdx.x >> 6) * (BVH_STACK * 64) + lane;
+    ws.top = (lds_v4f_ptr)top_mem;
+    ws.n_top = bvh_stage_top(bv, top_mem);
+    BvhCounters bc;
+    bc.nodes = 0; bc.tris = 0;
+    const uint32_t total = b.n_ext[q_in][wave];
+    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)wave * b.region_cap;
+    uint32_t next = 0, id = 0;
+    bool busy = false;
+    TravState ts;
+    ts.node = 0; ts.sp = 0; ts.run = false;
+    Ray ray;
+    ray.o = ray.d = mk3(0.0f, 0.0f, 0.0f);
+    BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    ClosestFold cf;
+    closest_fold_reset(cf, 1.0f);
+    for (;;) {
+        uint32_t nid = 0;
+        if (refill_take(q, total, next, busy, nid)) {
+            id = nid;
+            const float4 a = b.s0[id], c = b.s1[id];
+            ray.o = mk3(a.x, a.y, a.z);
+            ray.d = mk3(a.w, c.x, c.y);
+            br = bvh_ray_setup(ray, bv.max_abs_coord);
+            closest_fold_reset(cf, 1.0f);
+            busy = true;
+            ts.node = 0; ts.sp = 0; ts.run = br.finite;
+        }
+        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
+        auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ray, slot, 0, sc.count, -1, cf); return true; };
+        auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
+        bvh_advance(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
+        const bool fin = busy && !ts.run;
+        closest_fold_redo(sc, ray, fin && (!br.finite || cf.n_near > 2), 0, sc.count, -1, 1.0f, cf);
+        if (fin) {
+            const float inv_det = 1.0f / cf.st.w;
+            b.h0[id] = make_float4(cf.st.x * inv_det, cf.st.y * inv_det, cf.st.z * inv_det, __int_as_float(cf.best));
+        }
+        busy = busy && ts.run;
+    }
+    wstat_add(b, WSTAT_RAYS, total);
+    wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
+    wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
+}
+
 // Sum of one array of region fill counts (for the host's early stop).
 __global__ __launch_bounds__(256) void k_sum_counts(const uint32_t *__restrict__ counts, int n, uint32_t *__restrict__ out) {
     __shared__ uint32_t part[4];
@@ -559,14 +869,16 @@ struct Pipeline {
 
     // Renders the `n` samples listed in d_samples and adds them to `sum`.
     hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
-                   const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, rt_stats *host_stats,
-                   const char **what);
+                   const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
+                   rt_stats *host_stats, const char **what);
 };
 
 inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
-                                const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused,
+                                const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
                                 rt_stats *host_stats, const char **what) {
     const bool use_bvh = bvh.enabled != 0;
+    // lane refill needs the hierarchy; it shades depth >= 1 in a kernel of its own
+    const bool use_refill = use_bvh && refill && fused;
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
     const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
     const uint32_t pps = tiles * 64u;
@@ -611,7 +923,14 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
 #define LAUNCH_EXTEND(F, FU, BV)                                                                                        \
     hipLaunchKernelGGL((k_extend<F, FU, BV>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples, d_coins, \
                        pps, (uint32_t)n, max_depth)
-        if (fused) {
+        if (use_refill && depth > 0) {
+            hipLaunchKernelGGL(k_extend_refill, grid, block, 0, stream, sc, bvh, buf, q_in);
+            PIPE_TRY(hipGetLastError());
+            PIPE_TRY(stamp(2));
+            hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins, pps,
+                               (uint32_t)n, max_depth);
+            PIPE_TRY(hipGetLastError());
+        } else if (fused) {
             if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, true, true); else LAUNCH_EXTEND(true, true, false); }
             else { if (use_bvh) LAUNCH_EXTEND(false, true, true); else LAUNCH_EXTEND(false, true, false); }
             PIPE_TRY(hipGetLastError());
@@ -630,7 +949,9 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         }
 #undef LAUNCH_EXTEND
         PIPE_TRY(stamp(1));
-        if (use_bvh) {
+        if (use_refill) {
+            hipLaunchKernelGGL(k_probe_refill, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
+        } else if (use_bvh) {
             hipLaunchKernelGGL(k_probe_shadow<true>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
             PIPE_TRY(hipGetLastError());
             hipLaunchKernelGGL(k_probe_glossy<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);

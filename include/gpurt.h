@@ -169,6 +169,8 @@ int rt_reset_stats(rt_context *ctx);
  *   "accel"         -1 = bounding-volume hierarchy for scenes of 64 triangles or more (default),
  *                   0 = the reference's loops over all triangles, 1 = hierarchy always; results are identical
  *   "fuse_shade"    1 = the closest-hit kernel also shades its paths (default), 0 = separate shade kernel
+ *   "refill"        1 = traversal kernels hand finished lanes new rays (needs the hierarchy and fuse_shade = 1),
+ *                   0 = every wave processes its queue in chunks of 64 (default)
  *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
 int rt_set_option(rt_context *ctx, const char *name, int64_t value);
 

@@ -24,10 +24,12 @@ def _upload(ctx, scene, env):
 
 
 def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM):
-    # pipeline 0 = single kernel, 1 = staged with fused shading, 2 = staged with a separate shade kernel,
-    # 3 = staged, loops over all triangles instead of the hierarchy (1 and 2 use the hierarchy)
+    # pipeline 0 = single kernel, 1 = staged (default: hierarchy, fused shading), 2 = staged with a separate shade
+    # kernel at every depth, 3 = staged, loops over all triangles instead of the hierarchy, 4 = staged, hierarchy,
+    # traversal kernels with lane refill
     ctx.set_option("fuse_shade", 0 if pipeline == 2 else 1)
     ctx.set_option("accel", 0 if pipeline == 3 else 1)
+    ctx.set_option("refill", 1 if pipeline == 4 else 0)
     pipeline = min(pipeline, 1)
     ctx.set_option("pipeline", pipeline)
     ctx.set_option("batch_samples", batch)
@@ -111,7 +113,7 @@ def test_hierarchy_equals_index_order_loop(gpu_ctx, name):
 REF_IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close"]
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", REF_IMAGE_CASES)
 def test_images_equal_reference_shader(gpu_ctx, case, pipeline):
     """Images the reference's main() wrote for single SAMPLE values, bit for bit.  The reference stores
@@ -160,7 +162,7 @@ def test_mean_equals_reference_running_mean(gpu_ctx):
     assert np.allclose(total / 16.0, want, rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4])
 def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
     _upload(gpu_ctx, cubes, constant_env())
     for spp in (1, 4, 16):
@@ -170,7 +172,7 @@ def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
         assert [st["pixel_samples"], st["rays"], st["shadow_probes"], st["glossy_probes"]] == g["stats"].tolist()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4])
 def test_image_vs_checker_gradient_env_ragged(gpu_ctx, oracle_mod, cubes, pipeline):
     # 52 x 37 is not a multiple of the 8 x 8 tile; the gradient environment exercises the bilinear lookup
     _upload(gpu_ctx, cubes, gradient_env())
@@ -196,7 +198,7 @@ def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
     sc.upload_env(gradient_env())
     cam = camera_matrix((0.0, 1.0, -2.0), (-0.3, 0.0))
     want, wst = sc.render(cam, DEFAULT_CLOCK, 16, 1.0, 32, 24, 0, 3)
-    for pipeline in (0, 1, 2, 3):
+    for pipeline in (0, 1, 2, 3, 4):
         img, st = _render(gpu_ctx, 32, 24, 0, 3, recursion=16, pipeline=pipeline, batch=2, cam=cam)
         assert np.array_equal(img, want, equal_nan=True), pipeline
         assert st["rays"] == wst["rays"] and st["glossy_probes"] == wst["glossy_probes"]
@@ -251,7 +253,7 @@ def test_textured_materials_bit_exact(gpu_ctx, oracle_mod):
         target.set_has_texture(flags)
     clock, recursion = int(g["clock"]), int(g["recursion"])
     want, wst = sc.render(g["camera"], clock, recursion, 1.0, 48, 32, 0, 4)
-    for pipeline in (0, 1, 2, 3):
+    for pipeline in (0, 1, 2, 3, 4):
         img, st = _render(gpu_ctx, 48, 32, 0, 4, clock=clock, recursion=recursion, pipeline=pipeline, cam=g["camera"])
         assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
         assert st["rays"] == wst["rays"]
@@ -331,7 +333,7 @@ def test_synthetic_height_field_textured(gpu_ctx, oracle_mod, tmp_path):
                 target.upload_atlas_layer(m, k, layers[k])
         target.set_has_texture(flags)
     want, wst = sc.render(cam, 777, 6, 1.0, 64, 40, 0, 2)
-    for pipeline in (1, 3):
+    for pipeline in (1, 3, 4):
         img, st = _render(gpu_ctx, 64, 40, 0, 2, clock=777, pipeline=pipeline, cam=cam)
         assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
         assert st["rays"] == wst["rays"] and st["shadow_probes"] == wst["shadow_probes"]
