@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--workload", choices=("cubes", "obiwan", "c3"), default="cubes")
     ap.add_argument("--grid", type=int, default=724, help="c3: cells per side of the height field")
     ap.add_argument("--atlas", type=int, default=1024, help="c3: edge of the texture layers")
+    ap.add_argument("--refill", type=int, default=-1, help="-1 library default, 0/1 traversal kernels without/with lane refill")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
@@ -137,6 +138,8 @@ def main():
     ctx.set_option("batch_samples", args.batch_samples)
     ctx.set_option("fuse_shade", args.fuse_shade)
     ctx.set_option("accel", args.accel)
+    if args.refill >= 0:
+        ctx.set_option("refill", args.refill)
     ctx.set_option("profiling", 1)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)

@@ -61,7 +61,7 @@ struct rt_context {
     int batch_samples = 16;
     int profiling = 0;
     int fuse_shade = 1;
-    int refill = 0;
+    int refill = -1;           // -1 auto (lane refill from REFILL_AUTO_MIN triangles on), 0 off, 1 on
 
     // stats
     DStats *d_stats = nullptr;
@@ -115,6 +115,8 @@ DScene device_scene(const rt_context *ctx) {
 }
 
 constexpr int ACCEL_AUTO_MIN = 64;
+// Lane refill pays once traversals are long: +18 % on a 1 M-triangle scene, -14 % on a 424-triangle one.
+constexpr int REFILL_AUTO_MIN = 65536;
 
 DBvh device_bvh(const rt_context *ctx, const rt_context::DevBvh &b, bool want) {
     DBvh d;
@@ -529,7 +531,9 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
             const bool acc = use_accel(ctx);
             hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame,
                                          ctx->d_sum, ctx->d_samples, (int)n, ctx->stream, ctx->profiling != 0,
-                                         ctx->fuse_shade != 0, ctx->refill != 0, &ctx->host_stats, &msg);
+                                         ctx->fuse_shade != 0,
+                                         ctx->refill < 0 ? ctx->count >= REFILL_AUTO_MIN : ctx->refill != 0,
+                                         &ctx->host_stats, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
                             msg ? msg : "pipeline", hipGetErrorString(e));
@@ -701,7 +705,7 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "fuse_shade")) {
         ctx->fuse_shade = value ? 1 : 0;
     } else if (!strcmp(name, "refill")) {
-        ctx->refill = value ? 1 : 0;
+        ctx->refill = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(name, "profiling")) {
         ctx->profiling = value ? 1 : 0;
     } else {

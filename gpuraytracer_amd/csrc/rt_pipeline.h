@@ -3,28 +3,36 @@
 // The reference walks a whole path in one shader invocation (raytracer.glsl:440-584).  Paths
 // of one wave end at different depths and only some of them need a probe loop, so a wave that
 // keeps its 64 pixels for the whole walk soon runs mostly idle lanes through the O(COUNT)
-// loops.  Here a bounce is split into stages that each run as their own kernel over a densely
-// packed queue of path ids:
+// loops.  Here a bounce is split into stages that each run as their own kernel over densely
+// packed queues:
 //
 //   extend   closest hit (findIntersection) + everything of the bounce up to the probe loop;
-//            paths that need a probe are appended to the shadow or the glossy queue, paths that
-//            need none are finished (roulette) and appended to the next extend queue
+//            paths that need a probe go to the shadow or the glossy queue, paths that need none
+//            are finished (roulette) and go to the next extend queue
 //   shadow   occlusion loop of sampleLight + rest of the bounce        -> next extend queue
 //   glossy   search loop of sampleLightGlossy + rest of the bounce     -> next extend queue
 //   resolve  adds the radiance of the batch's paths to the per-pixel sums in ascending sample order
 //
-// Queues are filled with one atomic per wave (ballot + mbcnt compaction).  The order of ids in a
-// queue varies from run to run, but a path's arithmetic depends on its own state only and the
-// resolve stage adds in a fixed order, so results are reproducible bit for bit.
+// A queue entry is the path's whole state (a record), not an index into a state array: the survivors of a
+// bounce are a sparse subset of the paths, and gathering 16-byte fields of every fifth path from planes
+// indexed by path id made the stages of depth >= 1 wait on HBM (each 16-byte field costs a whole memory
+// sector; measured: 223 cycles of the vector memory path per load instruction).  Records are written
+// by the producer at consecutive positions of its own queue region and read back by the consumer with
+// consecutive lanes on consecutive records.
 //
-// Path state lives in HBM as structure-of-arrays float4 planes indexed by path id:
-//   s0 = (o.xyz, d.x)  s1 = (d.yz, path.xy)  s2 = (path.z, energy.xyz)
-//   s3 = (seed, current triangle | kept flags << 30)
-//   p0 = (probe_d.xyz, max_t)
-//   p1 = (lit.xyz, roughness), p2 = (albedo.xyz, -) for shadow probes; p1 = (specular.xyz, w) for glossy probes
-//   kd = kept_diff.xyz, ks = kept_spec.xyz   (see struct PathState); read only when the matching flag
-//        in s3 says they were ever written, so the planes need no clearing between batches
-//   h0 = (u, v, t, hit triangle id)          written by extend, read by shade
+// Record planes (structure of arrays, one float4/uint4 per record and plane):
+//   path record   xa = (o.xyz, d.x)  xb = (d.yz, path.xy)  xc = (path.z, energy.xyz)
+//                 xd = (seed, path id, kept flags, -)
+//   probe record  pa, pb, pc as above (state after the bounce's direction change)
+//                 pd = (seed, path id, current triangle | kept flags << 30, closest light of glossy pass 1)
+//                 p0 = (probe_d.xyz, max_t)
+//                 p1 = (lit.xyz, roughness), p2 = (albedo.xyz, -) for shadow probes
+//                 p1 = (specular.xyz, w), p2 = (x, y, rd, det) of the closest light for glossy probes
+//   Shadow records fill a region of the probe queue from its front, glossy records from its back.
+// By path id:     energy = radiance of a path that has ended (written once, read by resolve)
+//                 kd, ks = kept light results (see struct PathState), touched only when their flag is set
+//                 h0     = (u, v, t, hit triangle id) of the unfused form at depth 0; at depth >= 1 h0 is
+//                          indexed like the extend queue being read
 // Path id = slot * paths_per_sample + tile * 64 + lane, where `slot` is the sample's position in
 // the batch and (tile, lane) is the 8x8 pixel tile and the pixel inside it, so that the depth-0
 // wave holds the same 64 pixels as a reference workgroup.
@@ -58,9 +66,11 @@ RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
 // entries always suffices.  With one atomic per wave and queue on three shared counters the shade
 // stage spent 87 % of its time waiting (2.2 ms for 8.3 M paths); the regions took that away.
 struct PipeBuffers {
-    float4 *s0, *s1, *s2, *p0, *p1, *p2, *kd, *ks, *h0;
-    uint2 *s3;
-    uint32_t *q_ext[2], *q_shadow, *q_glossy;   // PIPE_WAVES regions of region_cap path ids each
+    float4 *xa[2], *xb[2], *xc[2];              // extend queues (ping-pong): path records
+    uint4 *xd[2];
+    float4 *pa, *pb, *pc, *p0, *p1, *p2;        // probe queue: shadow records from the front of a region, glossy from its back
+    uint4 *pd;
+    float4 *h0, *energy, *kd, *ks;
     uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
     uint32_t region_cap;
     unsigned long long *wstats;                 // [PIPE_WAVES][8] per-wave work counters (see WSTAT_*)
@@ -70,28 +80,50 @@ struct PipeBuffers {
 enum { WSTAT_PATHS = 0, WSTAT_RAYS, WSTAT_SHADOW, WSTAT_GLOSSY, WSTAT_EXT_NODES, WSTAT_EXT_TRIS, WSTAT_PROBE_NODES,
        WSTAT_PROBE_TRIS };
 
-RT_DEV void load_path(const PipeBuffers &b, uint32_t id, PathState &ps) {
-    const float4 a = b.s0[id], c = b.s1[id], e = b.s2[id];
+constexpr uint32_t KEPT_DIFF = 1u, KEPT_SPEC = 2u;      // kept flags
+constexpr uint32_t CURRENT_MASK = 0x3FFFFFFFu;
+
+RT_DEV void unpack_path(float4 a, float4 c, float4 e, PathState &ps) {
     ps.o = mk3(a.x, a.y, a.z);
     ps.d = mk3(a.w, c.x, c.y);
     ps.path = mk3(c.z, c.w, e.x);
     ps.energy = mk3(e.y, e.z, e.w);
 }
-constexpr uint32_t KEPT_DIFF = 1u, KEPT_SPEC = 2u;      // flag bits kept in s3.y >> 30
-constexpr uint32_t CURRENT_MASK = 0x3FFFFFFFu;
-
-RT_DEV void store_path(const PipeBuffers &b, uint32_t id, const PathState &ps) {
-    b.s0[id] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-    b.s1[id] = make_float4(ps.d.y, ps.d.z, ps.path.x, ps.path.y);
-    b.s2[id] = make_float4(ps.path.z, ps.energy.x, ps.energy.y, ps.energy.z);
+RT_DEV void load_path_rec(const PipeBuffers &b, int q, size_t i, PathState &ps, uint32_t &id, uint32_t &kept_flags) {
+    unpack_path(b.xa[q][i], b.xb[q][i], b.xc[q][i], ps);
+    const uint4 d = b.xd[q][i];
+    ps.seed = d.x;
+    id = d.y;
+    kept_flags = d.z;
+}
+RT_DEV void store_path_rec(const PipeBuffers &b, int q, size_t i, const PathState &ps, uint32_t id, uint32_t kept_flags) {
+    b.xa[q][i] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+    b.xb[q][i] = make_float4(ps.d.y, ps.d.z, ps.path.x, ps.path.y);
+    b.xc[q][i] = make_float4(ps.path.z, ps.energy.x, ps.energy.y, ps.energy.z);
+    b.xd[q][i] = make_uint4(ps.seed, id, kept_flags, 0u);
+}
+// The path part of a probe record (what finish_diffuse / finish_glossy go on with).
+RT_DEV void load_probe_path(const PipeBuffers &b, size_t i, PathState &ps) { unpack_path(b.pa[i], b.pb[i], b.pc[i], ps); }
+// A path that has ended leaves its radiance for the resolve stage.
+RT_DEV void finish_path(const PipeBuffers &b, uint32_t id, const PathState &ps) {
+    b.energy[id] = make_float4(ps.energy.x, ps.energy.y, ps.energy.z, 0.0f);
 }
 
-// Appends `id` of every lane with `pred` to this wave's queue region; `fill` is wave-uniform.
-RT_DEV void region_push(uint32_t *__restrict__ region, uint32_t &fill, bool pred, uint32_t id) {
+// Position in this wave's queue region for every lane with `pred`; `fill` is wave-uniform.
+RT_DEV uint32_t region_slot(uint32_t &fill, bool pred) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(pred);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    if (pred) region[fill + rank] = id;
+    const uint32_t slot = fill + rank;
     fill += (uint32_t)__popcll(mask);
+    return slot;
+}
+// Hands a path on to the next extend queue, or ends it.  Whole waves call it; `live` masks lanes.
+RT_DEV void route_next(const PipeBuffers &b, int q_out, uint32_t &fill_next, bool live, bool go_on, const PathState &ps,
+                       uint32_t id, uint32_t kept_flags) {
+    const bool cont = live && go_on;
+    const uint32_t slot = region_slot(fill_next, cont);
+    if (cont) store_path_rec(b, q_out, (size_t)wave_index() * b.region_cap + slot, ps, id, kept_flags);
+    if (live && !go_on) finish_path(b, id, ps);
 }
 
 RT_DEV void wstat_add(const PipeBuffers &b, int which, unsigned long long v) {
@@ -101,46 +133,51 @@ RT_DEV void wstat_add(const PipeBuffers &b, int which, unsigned long long v) {
 struct RouteFill { uint32_t shadow, glossy, next; };
 
 // Shading of one path after its closest hit is known (raytracer.glsl:452-556): adds the sky on a
-// miss, otherwise runs shade_pre and routes the path to the shadow queue, the glossy queue or (no
-// probe needed) through shade_post to the next extend queue.  Called by whole waves; `live` masks lanes.
+// miss, otherwise runs shade_pre and hands the path to the shadow queue, the glossy queue or (no
+// probe needed) through the rest of the bounce to the next extend queue.  Called by whole waves.
 RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffers &b, int depth, int q_in,
                             const uint32_t *__restrict__ coins, uint32_t paths_per_sample, int max_depth, bool live,
                             uint32_t id, PathState &ps, uint32_t kept_flags, int hit, float hu, float hv, float ht,
                             RouteFill &fill) {
-    bool to_shadow = false, to_glossy = false, to_next = false;
+    bool to_shadow = false, to_glossy = false, go_on = false;
+    Bounce bn;
+    bn.kind = PROBE_NONE;
     if (live) {
         if (hit < 0) {
             ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
         } else {
             const uint32_t slot = id / paths_per_sample;
             const bool coin_diffuse = coins[slot * (uint32_t)max_depth + (uint32_t)depth] != 0u;
-            Bounce bn;
             shade_pre(sc, fr, ps, hit, hu, hv, ht, coin_diffuse, bn);
             if (bn.kind == PROBE_NONE) {
                 // sampleLight returned false before its occlusion loop: the kept light enters the roulette
                 ps.kept_diff = mk3(0.0f, 0.0f, 0.0f);
                 if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
-                to_next = finish_diffuse(sc, ps, hit, false, bn.lit, bn.albedo, bn.roughness);
+                go_on = finish_diffuse(sc, ps, hit, false, bn.lit, bn.albedo, bn.roughness) && (depth + 1 < max_depth);
             } else {
-                b.p0[id] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
-                if (bn.kind == PROBE_SHADOW) {
-                    b.p1[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, bn.roughness);
-                    b.p2[id] = make_float4(bn.albedo.x, bn.albedo.y, bn.albedo.z, 0.0f);
-                } else {
-                    b.p1[id] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
-                }
                 to_shadow = bn.kind == PROBE_SHADOW;
                 to_glossy = bn.kind == PROBE_GLOSSY;
             }
-            b.s3[id] = make_uint2(ps.seed, (uint32_t)hit | (kept_flags << 30));
         }
-        store_path(b, id, ps);
     }
-    to_next = to_next && (depth + 1 < max_depth);
-    const size_t region = (size_t)wave_index() * b.region_cap;
-    region_push(b.q_shadow + region, fill.shadow, to_shadow, id);
-    region_push(b.q_glossy + region, fill.glossy, to_glossy, id);
-    region_push(b.q_ext[q_in ^ 1] + region, fill.next, to_next, id);
+    const size_t base = (size_t)wave_index() * b.region_cap;
+    const uint32_t s_slot = region_slot(fill.shadow, to_shadow);
+    const uint32_t g_slot = region_slot(fill.glossy, to_glossy);
+    if (to_shadow | to_glossy) {
+        const size_t i = to_shadow ? base + s_slot : base + (b.region_cap - 1u - g_slot);
+        b.pa[i] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+        b.pb[i] = make_float4(ps.d.y, ps.d.z, ps.path.x, ps.path.y);
+        b.pc[i] = make_float4(ps.path.z, ps.energy.x, ps.energy.y, ps.energy.z);
+        b.pd[i] = make_uint4(ps.seed, id, (uint32_t)hit | (kept_flags << 30), 0xFFFFFFFFu);
+        b.p0[i] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
+        if (to_shadow) {
+            b.p1[i] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, bn.roughness);
+            b.p2[i] = make_float4(bn.albedo.x, bn.albedo.y, bn.albedo.z, 0.0f);
+        } else {
+            b.p1[i] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
+        }
+    }
+    route_next(b, q_in ^ 1, fill.next, live && !(to_shadow | to_glossy), go_on, ps, id, kept_flags);
 }
 
 RT_DEV void store_route_fill(const PipeBuffers &b, int q_in, const RouteFill &fill) {
@@ -152,10 +189,27 @@ RT_DEV void store_route_fill(const PipeBuffers &b, int q_in, const RouteFill &fi
     }
 }
 
+// Camera path of queue position `qi` at depth 0 (raytracer.glsl:586-607).  Returns false for the padding
+// lanes of ragged tiles.
+RT_DEV bool first_path(const DFrame &fr, const uint32_t *__restrict__ samples, uint32_t paths_per_sample, uint32_t tiles_x,
+                       uint32_t qi, bool live, PathState &ps) {
+    const uint32_t lane = lane_index();
+    const uint32_t slot = live ? qi / paths_per_sample : 0u;
+    const uint32_t tile = (qi - slot * paths_per_sample) >> 6;
+    const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
+    const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
+    ps.seed = pixel_seed(fr, tx, ty, samples[slot]);
+    const Ray cam = camera_ray(fr, tx, ty, ps.seed);
+    ps.o = cam.o; ps.d = cam.d;
+    ps.path = mk3(1.0f, 1.0f, 1.0f);
+    ps.energy = mk3(0.0f, 0.0f, 0.0f);
+    return live && (tx < fr.width) && (ty < fr.height);
+}
+
 // Extend stage: the closest-hit search.  FIRST: depth 0, the wave generates the camera rays of its
-// pixels itself (raytracer.glsl:586-607) instead of reading a queue.  FUSED: the wave goes on to
-// shade its paths; otherwise it writes the hit record h0 = (u, v, t, triangle id; -1 = miss) and
-// k_shade does the shading.  BVH: hierarchy traversal instead of the loop over all triangles.
+// pixels itself instead of reading a queue.  FUSED: the wave goes on to shade its paths; otherwise it
+// writes the hit record h0 = (u, v, t, triangle id; -1 = miss) and k_shade does the shading.  BVH:
+// hierarchy traversal instead of the loop over all triangles.
 template <bool FIRST, bool FUSED, bool BVH>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
                                                           const uint32_t *__restrict__ samples,
@@ -163,7 +217,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
                                                           uint32_t n_slots, int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
     const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][wave];
-    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)wave * b.region_cap;
+    const size_t region = (size_t)wave * b.region_cap;
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
     __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
     __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
@@ -177,7 +231,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
 
-    // FIRST: chunks blockIdx, blockIdx + PIPE_WAVES, ... of the identity queue; else this wave's region
+    // FIRST: chunks wave, wave + PIPE_WAVES, ... of the identity queue; else this wave's region
     for (uint32_t base = FIRST ? wave * 64u : 0u; base < total; base += FIRST ? (uint32_t)PIPE_WAVES * 64u : 64u) {
         const uint32_t qi = base + lane;
         bool live = qi < total;
@@ -185,32 +239,15 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
         PathState ps;
         if (FIRST) {
             id = qi;
-            const uint32_t slot = live ? id / paths_per_sample : 0u;
-            const uint32_t local = id - slot * paths_per_sample;
-            const uint32_t tile = local >> 6;
-            const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
-            const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
-            const bool in_image = (tx < fr.width) && (ty < fr.height);
-            ps.seed = pixel_seed(fr, tx, ty, samples[slot]);
-            const Ray cam = camera_ray(fr, tx, ty, ps.seed);
-            ps.o = cam.o; ps.d = cam.d;
-            ps.path = mk3(1.0f, 1.0f, 1.0f);
-            ps.energy = mk3(0.0f, 0.0f, 0.0f);
-            if (live && !in_image) store_path(b, id, ps);   // padding lanes of ragged tiles: energy 0 for the resolve stage
-            live = live && in_image;
+            live = first_path(fr, samples, paths_per_sample, tiles_x, qi, live, ps);
             n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
+        } else if (FUSED) {
+            load_path_rec(b, q_in, region + (live ? qi : 0u), ps, id, kept_flags);
         } else {
-            id = live ? q[qi] : 0u;
-            if (FUSED) {
-                load_path(b, id, ps);
-                const uint2 s3v = b.s3[id];
-                ps.seed = s3v.x;
-                kept_flags = s3v.y >> 30;
-            } else {
-                const float4 a = b.s0[id], c = b.s1[id];
-                ps.o = mk3(a.x, a.y, a.z);
-                ps.d = mk3(a.w, c.x, c.y);
-            }
+            const size_t i = region + (live ? qi : 0u);
+            const float4 a = b.xa[q_in][i], c = b.xb[q_in][i];
+            ps.o = mk3(a.x, a.y, a.z);
+            ps.d = mk3(a.w, c.x, c.y);
         }
         n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
@@ -222,7 +259,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
             shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, kept_flags, hit,
                             isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, fill);
         } else if (live) {
-            b.h0[id] = make_float4(isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, __int_as_float(hit));
+            b.h0[FIRST ? (size_t)qi : region + qi] =
+                make_float4(isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, __int_as_float(hit));
         }
     }
     if (FUSED) store_route_fill(b, q_in, fill);
@@ -242,7 +280,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, P
                                                          uint32_t n_slots, int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
     const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][wave];
-    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)wave * b.region_cap;
+    const size_t region = (size_t)wave * b.region_cap;
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
@@ -252,31 +290,73 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, P
         bool live = qi < total;
         uint32_t id = 0, kept_flags = 0;
         PathState ps;
+        size_t hi;
         if (FIRST) {
             // the camera ray is cheap to regenerate (raytracer.glsl:594-606): no state was stored for depth 0
             id = live ? qi : 0u;
-            const uint32_t slot = id / paths_per_sample;
-            const uint32_t tile = (id - slot * paths_per_sample) >> 6;
-            const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
-            const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
-            live = live && (tx < fr.width) && (ty < fr.height);
-            ps.seed = pixel_seed(fr, tx, ty, samples[slot]);
-            const Ray cam = camera_ray(fr, tx, ty, ps.seed);
-            ps.o = cam.o; ps.d = cam.d;
-            ps.path = mk3(1.0f, 1.0f, 1.0f);
-            ps.energy = mk3(0.0f, 0.0f, 0.0f);
+            live = first_path(fr, samples, paths_per_sample, tiles_x, id, live, ps);
+            hi = id;
         } else {
-            id = live ? q[qi] : 0u;
-            load_path(b, id, ps);
-            const uint2 s3v = b.s3[id];
-            ps.seed = s3v.x;
-            kept_flags = s3v.y >> 30;
+            hi = region + (live ? qi : 0u);
+            load_path_rec(b, q_in, hi, ps, id, kept_flags);
         }
-        const float4 h = b.h0[id];
+        const float4 h = b.h0[hi];
         shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, kept_flags,
                         __float_as_int(h.w), h.x, h.y, h.z, fill);
     }
     store_route_fill(b, q_in, fill);
+}
+
+// What the probe stages read of a probe record before the search.
+struct ProbeHead {
+    Ray probe;
+    float max_t;
+    uint32_t seed, id, kept_flags;
+    int current, light_id;
+};
+RT_DEV void load_probe_head(const PipeBuffers &b, size_t i, ProbeHead &h) {
+    const float4 a = b.pa[i], pr = b.p0[i];
+    const uint4 d = b.pd[i];
+    h.probe.o = mk3(a.x, a.y, a.z);
+    h.probe.d = mk3(pr.x, pr.y, pr.z);
+    h.max_t = pr.w;
+    h.seed = d.x;
+    h.id = d.y;
+    h.current = (int)(d.z & CURRENT_MASK);
+    h.kept_flags = d.z >> 30;
+    h.light_id = (int)d.w;
+}
+// Rest of a bounce after its shadow probe (raytracer.glsl:557-579).  Returns whether the path goes on.
+RT_DEV bool retire_shadow(const DScene &sc, const PipeBuffers &b, size_t i, const ProbeHead &h, bool blocked, PathState &ps,
+                          uint32_t &kept_flags) {
+    load_probe_path(b, i, ps);
+    ps.seed = h.seed;
+    const float4 c = b.p1[i], al = b.p2[i];
+    kept_flags = h.kept_flags;
+    ps.kept_diff = mk3(0.0f, 0.0f, 0.0f);
+    if (blocked) {
+        if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[h.id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
+    } else {
+        b.kd[h.id] = make_float4(c.x, c.y, c.z, 0.0f);
+        kept_flags |= KEPT_DIFF;
+    }
+    return finish_diffuse(sc, ps, h.current, !blocked, mk3(c.x, c.y, c.z), mk3(al.x, al.y, al.z), c.w);
+}
+// Rest of a bounce after its glossy probe (raytracer.glsl:420-437, :557-579).
+RT_DEV bool retire_glossy(const DScene &sc, const DFrame &fr, const PipeBuffers &b, size_t i, const ProbeHead &h, int outcome,
+                          int light_id, f4 lsec, PathState &ps, uint32_t &kept_flags) {
+    load_probe_path(b, i, ps);
+    ps.seed = h.seed;
+    const float4 c = b.p1[i];
+    kept_flags = h.kept_flags;
+    ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
+    if (outcome == 0 && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[h.id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
+    const bool go_on = finish_glossy(sc, fr, ps, h.current, outcome, h.probe.d, light_id, lsec, mk3(c.x, c.y, c.z), c.w);
+    if (outcome != 0) {
+        b.ks[h.id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
+        kept_flags |= KEPT_SPEC;
+    }
+    return go_on;
 }
 
 // Shadow-probe stage: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579.
@@ -295,38 +375,19 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh 
     const size_t region = (size_t)wave * b.region_cap;
     const uint32_t total = b.n_shadow[wave];
     uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
+    const bool deeper = depth + 1 < max_depth;
     for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t qi = base + lane;
-        const bool live = qi < total;
-        const uint32_t id = live ? b.q_shadow[region + qi] : 0u;
-        const float4 a = b.s0[id], pr = b.p0[id];
-        const uint2 sc3 = b.s3[id];
-        Ray probe;
-        probe.o = mk3(a.x, a.y, a.z);
-        probe.d = mk3(pr.x, pr.y, pr.z);
-        const int current = (int)(sc3.y & CURRENT_MASK);
-        uint32_t kept_flags = sc3.y >> 30;
-        const bool blocked = BVH ? shadow_any_hit_bvh(sc, bv, probe, pr.w, current, live, ws, bc)
-                                 : shadow_any_hit_bf(sc, probe, pr.w, current, live);
-        bool to_next = false;
-        if (live) {
-            PathState ps;
-            load_path(b, id, ps);
-            ps.seed = sc3.x;
-            const float4 c = b.p1[id], al = b.p2[id];
-            ps.kept_diff = mk3(0.0f, 0.0f, 0.0f);
-            if (blocked) {
-                if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
-            } else {
-                b.kd[id] = make_float4(c.x, c.y, c.z, 0.0f);
-                kept_flags |= KEPT_DIFF;
-            }
-            to_next = finish_diffuse(sc, ps, current, !blocked, mk3(c.x, c.y, c.z), mk3(al.x, al.y, al.z), c.w);
-            store_path(b, id, ps);
-            b.s3[id] = make_uint2(ps.seed, (uint32_t)current | (kept_flags << 30));
-        }
-        to_next = to_next && (depth + 1 < max_depth);
-        region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next, id);
+        const bool live = base + lane < total;
+        const size_t i = region + (live ? base + lane : 0u);
+        ProbeHead h;
+        load_probe_head(b, i, h);
+        const bool blocked = BVH ? shadow_any_hit_bvh(sc, bv, h.probe, h.max_t, h.current, live, ws, bc)
+                                 : shadow_any_hit_bf(sc, h.probe, h.max_t, h.current, live);
+        PathState ps;
+        uint32_t kept_flags = 0;
+        bool go_on = false;
+        if (live) go_on = retire_shadow(sc, b, i, h, blocked, ps, kept_flags) && deeper;
+        route_next(b, q_in ^ 1, fill_next, live, go_on, ps, h.id, kept_flags);
     }
     if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
     wstat_add(b, WSTAT_SHADOW, total);
@@ -350,41 +411,24 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const size_t region = (size_t)wave * b.region_cap;
+    const size_t last = region + b.region_cap - 1u;
     const uint32_t total = b.n_glossy[wave];
     uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
+    const bool deeper = depth + 1 < max_depth;
     for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t qi = base + lane;
-        const bool live = qi < total;
-        const uint32_t id = live ? b.q_glossy[region + qi] : 0u;
-        const float4 a = b.s0[id], pr = b.p0[id];
-        const uint2 sc3 = b.s3[id];
-        Ray probe;
-        probe.o = mk3(a.x, a.y, a.z);
-        probe.d = mk3(pr.x, pr.y, pr.z);
+        const bool live = base + lane < total;
+        const size_t i = last - (live ? base + lane : 0u);
+        ProbeHead h;
+        load_probe_head(b, i, h);
         int light_id;
         f4 lsec;
-        const int current = (int)(sc3.y & CURRENT_MASK);
-        uint32_t kept_flags = sc3.y >> 30;
-        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, probe, current, live, light_id, lsec, ws, bc)
-                                : glossy_search_bf(sc, probe, current, live, light_id, lsec);
-        bool to_next = false;
-        if (live) {
-            PathState ps;
-            load_path(b, id, ps);
-            ps.seed = sc3.x;
-            const float4 c = b.p1[id];
-            ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
-            if (outcome == 0 && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
-            to_next = finish_glossy(sc, fr, ps, current, outcome, probe.d, light_id, lsec, mk3(c.x, c.y, c.z), c.w);
-            if (outcome != 0) {
-                b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
-                kept_flags |= KEPT_SPEC;
-            }
-            store_path(b, id, ps);
-            b.s3[id] = make_uint2(ps.seed, (uint32_t)current | (kept_flags << 30));
-        }
-        to_next = to_next && (depth + 1 < max_depth);
-        region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next, id);
+        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, bc)
+                                : glossy_search_bf(sc, h.probe, h.current, live, light_id, lsec);
+        PathState ps;
+        uint32_t kept_flags = 0;
+        bool go_on = false;
+        if (live) go_on = retire_glossy(sc, fr, b, i, h, outcome, light_id, lsec, ps, kept_flags) && deeper;
+        route_next(b, q_in ^ 1, fill_next, live, go_on, ps, h.id, kept_flags);
     }
     if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
     wstat_add(b, WSTAT_GLOSSY, total);
@@ -398,16 +442,15 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
 // Traversal stages with lane refill.  Rays that start on surfaces are incoherent: in a wave that takes 64
 // queue entries and waits for the slowest, under a third of the lanes do useful work in the node loop.
 // Here a wave keeps its lanes busy instead: as soon as REFILL_MIN lanes have finished their ray, their
-// results are retired and the free lanes fetch the next entries of the wave's queue region while the other
-// lanes carry on where they were (bvh_advance keeps per-lane traversal state).  What is retired with a
-// partly filled wave is only the short rest of the bounce (or a 16-byte hit record), so the loss there is
-// small.  A path's arithmetic does not depend on which lane or in which order it is processed, and the
-// order of a queue region only decides the order of the next region, so results stay bit-identical.
+// results are retired and the free lanes take the next records of the wave's queue region while the other
+// lanes carry on where they were (bvh_advance keeps per-lane traversal state).  A path's arithmetic does
+// not depend on which lane or in which order it is processed, and the order of a queue region only
+// decides the order of the next region, so results stay bit-identical.
 constexpr int REFILL_MIN = 24;
 
-// Hands queue entries to the lanes that are not busy, once at least REFILL_MIN lanes are free.  Returns
-// true for the lanes that received an entry (in `id`).
-RT_DEV bool refill_take(const uint32_t *__restrict__ q, uint32_t total, uint32_t &next, bool busy, uint32_t &id) {
+// Hands queue positions to the lanes that are not busy, once at least REFILL_MIN lanes are free.  Returns
+// true for the lanes that received one (in `k`).
+RT_DEV bool refill_take(uint32_t total, uint32_t &next, bool busy, uint32_t &k) {
     const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     bool got = false;
@@ -415,13 +458,13 @@ RT_DEV bool refill_take(const uint32_t *__restrict__ q, uint32_t total, uint32_t
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
         const uint32_t avail = total - next;
         const uint32_t take = n_idle < avail ? n_idle : avail;
-        if (!busy && rank < take) { id = q[next + rank]; got = true; }
+        if (!busy && rank < take) { k = next + rank; got = true; }
         next += take;
     }
     return got;
 }
 
-// All light probes of one depth in one launch: the shadow queue, then the glossy queue in two passes
+// All light probes of one depth in one launch: the shadow records, then the glossy records in two passes
 // (closest light through the hierarchy over the emissive triangles; then the any-hit search over the
 // others, raytracer.glsl:403-419 in the two-phase form of glossy_search_bf).
 __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth,
@@ -438,37 +481,30 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh 
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const size_t region = (size_t)wave * b.region_cap;
+    const size_t last = region + b.region_cap - 1u;
     uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
     const bool deeper = depth + 1 < max_depth;
     const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
+    ProbeHead h;
+    h.probe.o = h.probe.d = mk3(0.0f, 0.0f, 0.0f);
+    h.max_t = 0.0f; h.seed = 0; h.id = 0; h.kept_flags = 0; h.current = -1; h.light_id = -1;
 
-    // ---- shadow queue: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579
+    // ---- shadow records: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579
     {
         const uint32_t total = b.n_shadow[wave];
-        const uint32_t *__restrict__ q = b.q_shadow + region;
-        uint32_t next = 0, id = 0, seed = 0, kept_flags = 0;
+        uint32_t next = 0;
+        size_t i = region;
         bool busy = false, ok = true, blocked = false;
         TravState ts;
         ts.node = 0; ts.sp = 0; ts.run = false;
-        Ray probe;
-        probe.o = probe.d = mk3(0.0f, 0.0f, 0.0f);
-        float max_t = 0.0f;
-        int current = -1;
-        BvhRay br = bvh_ray_setup(probe, bv.max_abs_coord);
+        BvhRay br = bvh_ray_setup(h.probe, bv.max_abs_coord);
         for (;;) {
-            uint32_t nid = 0;
-            if (refill_take(q, total, next, busy, nid)) {
-                id = nid;
-                const float4 a = b.s0[id], pr = b.p0[id];
-                const uint2 sc3 = b.s3[id];
-                probe.o = mk3(a.x, a.y, a.z);
-                probe.d = mk3(pr.x, pr.y, pr.z);
-                max_t = pr.w;
-                seed = sc3.x;
-                current = (int)(sc3.y & CURRENT_MASK);
-                kept_flags = sc3.y >> 30;
-                br = bvh_ray_setup(probe, bv.max_abs_coord);
-                ok = br.finite && ((max_t - max_t) == 0.0f);
+            uint32_t k = 0;
+            if (refill_take(total, next, busy, k)) {
+                i = region + k;
+                load_probe_head(b, i, h);
+                br = bvh_ray_setup(h.probe, bv.max_abs_coord);
+                ok = br.finite && ((h.max_t - h.max_t) == 0.0f);
                 blocked = false;
                 busy = true;
                 ts.node = 0; ts.sp = 0; ts.run = ok;
@@ -476,128 +512,97 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh 
             if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
             auto leaf = [&](int slot) -> bool {
                 const Tri t = load_leaf_tri(bv, slot);
-                if (intersect_triangle_shadow(probe, t, max_t) && leaf_tri_id(bv, slot) != current) { blocked = true; return false; }
+                if (intersect_triangle_shadow(h.probe, t, h.max_t) && leaf_tri_id(bv, slot) != h.current) { blocked = true; return false; }
                 return true;
             };
-            const float lim = max_t * BVH_NEAR;
+            const float lim = h.max_t * BVH_NEAR;
             auto limit = [&]() -> float { return lim; };
             bvh_advance(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
             const bool fin = busy && !ts.run;
             const bool redo = fin && !ok;
             if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-                const bool b2 = shadow_any_hit_bf(sc, probe, max_t, current, redo);
+                const bool b2 = shadow_any_hit_bf(sc, h.probe, h.max_t, h.current, redo);
                 if (redo) blocked = b2;
             }
-            bool to_next = false;
-            if (fin) {
-                PathState ps;
-                load_path(b, id, ps);
-                ps.seed = seed;
-                const float4 c = b.p1[id], al = b.p2[id];
-                ps.kept_diff = mk3(0.0f, 0.0f, 0.0f);
-                if (blocked) {
-                    if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
-                } else {
-                    b.kd[id] = make_float4(c.x, c.y, c.z, 0.0f);
-                    kept_flags |= KEPT_DIFF;
-                }
-                to_next = finish_diffuse(sc, ps, current, !blocked, mk3(c.x, c.y, c.z), mk3(al.x, al.y, al.z), c.w);
-                store_path(b, id, ps);
-                b.s3[id] = make_uint2(ps.seed, (uint32_t)current | (kept_flags << 30));
-            }
-            region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next && deeper, id);
+            PathState ps;
+            uint32_t kept_flags = 0;
+            bool go_on = false;
+            if (fin) go_on = retire_shadow(sc, b, i, h, blocked, ps, kept_flags) && deeper;
+            route_next(b, q_in ^ 1, fill_next, fin, go_on, ps, h.id, kept_flags);
             busy = busy && ts.run;
         }
         wstat_add(b, WSTAT_SHADOW, total);
     }
 
-    // ---- glossy queue, pass 1: closest emissive triangle -> p2 = its (x, y, rd, det), p0.w = its index
+    // ---- glossy records, pass 1: closest emissive triangle -> p2 = its (x, y, rd, det), pd.w = its index
     const uint32_t g_total = b.n_glossy[wave];
-    const uint32_t *__restrict__ gq = b.q_glossy + region;
     if (lbv.enabled) {
-        uint32_t next = 0, id = 0;
+        uint32_t next = 0;
+        size_t i = last;
         bool busy = false;
         TravState ts;
         ts.node = 0; ts.sp = 0; ts.run = false;
-        Ray probe;
-        probe.o = probe.d = mk3(0.0f, 0.0f, 0.0f);
-        int current = -1;
-        BvhRay br = bvh_ray_setup(probe, lbv.max_abs_coord);
+        BvhRay br = bvh_ray_setup(h.probe, lbv.max_abs_coord);
         ClosestFold cf;
         closest_fold_reset(cf, 0.0f);
         for (;;) {
-            uint32_t nid = 0;
-            if (refill_take(gq, g_total, next, busy, nid)) {
-                id = nid;
-                const float4 a = b.s0[id], pr = b.p0[id];
-                probe.o = mk3(a.x, a.y, a.z);
-                probe.d = mk3(pr.x, pr.y, pr.z);
-                current = (int)(b.s3[id].y & CURRENT_MASK);
-                br = bvh_ray_setup(probe, lbv.max_abs_coord);
+            uint32_t k = 0;
+            if (refill_take(g_total, next, busy, k)) {
+                i = last - k;
+                load_probe_head(b, i, h);
+                br = bvh_ray_setup(h.probe, lbv.max_abs_coord);
                 closest_fold_reset(cf, 0.0f);
                 busy = true;
                 ts.node = 0; ts.sp = 0; ts.run = br.finite;
             }
             if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
-            auto leaf = [&](int slot) -> bool { closest_fold_leaf(lbv, probe, slot, 0, lights, current, cf); return true; };
+            auto leaf = [&](int slot) -> bool { closest_fold_leaf(lbv, h.probe, slot, 0, lights, h.current, cf); return true; };
             auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
             bvh_advance(lbv, br, lws, ts, next < g_total ? REFILL_MIN : 65, leaf, limit, bc);
             const bool fin = busy && !ts.run;
-            closest_fold_redo(sc, probe, fin && (!br.finite || cf.n_near > 2), 0, lights, current, 0.0f, cf);
+            closest_fold_redo(sc, h.probe, fin && (!br.finite || cf.n_near > 2), 0, lights, h.current, 0.0f, cf);
             if (fin) {
-                b.p2[id] = make_float4(cf.st.x, cf.st.y, cf.st.z, cf.st.w);
-                ((float *)&b.p0[id])[3] = __int_as_float(cf.best);
+                b.p2[i] = make_float4(cf.st.x, cf.st.y, cf.st.z, cf.st.w);
+                ((uint32_t *)&b.pd[i])[3] = (uint32_t)cf.best;
             }
             busy = busy && ts.run;
         }
     } else {
         for (uint32_t base = 0; base < g_total; base += 64u) {
             const bool live = base + lane < g_total;
-            const uint32_t id = live ? gq[base + lane] : 0u;
-            const float4 a = b.s0[id], pr = b.p0[id];
-            Ray probe;
-            probe.o = mk3(a.x, a.y, a.z);
-            probe.d = mk3(pr.x, pr.y, pr.z);
-            const int current = (int)(b.s3[id].y & CURRENT_MASK);
+            const size_t i = last - (live ? base + lane : 0u);
+            load_probe_head(b, i, h);
             f4 isec;
             isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
-            const int light_id = closest_hit_range(sc.geo, 0, lights, probe, live, current, isec, -1);
+            const int light_id = closest_hit_range(sc.geo, 0, lights, h.probe, live, h.current, isec, -1);
             if (live) {
-                b.p2[id] = make_float4(isec.x, isec.y, isec.z, isec.w);
-                ((float *)&b.p0[id])[3] = __int_as_float(light_id);
+                b.p2[i] = make_float4(isec.x, isec.y, isec.z, isec.w);
+                ((uint32_t *)&b.pd[i])[3] = (uint32_t)light_id;
             }
         }
     }
     // the records of pass 1 are read back by other lanes of this wave: make them visible
     __threadfence();
 
-    // ---- glossy queue, pass 2: is any non-emissive triangle not farther than that light?  then :420-437, :557-579
+    // ---- glossy records, pass 2: is any non-emissive triangle not farther than that light?  then :420-437, :557-579
     {
-        uint32_t next = 0, id = 0, seed = 0, kept_flags = 0;
+        uint32_t next = 0;
+        size_t i = last;
         bool busy = false, ok = true, blocked = false;
         TravState ts;
         ts.node = 0; ts.sp = 0; ts.run = false;
-        Ray probe;
-        probe.o = probe.d = mk3(0.0f, 0.0f, 0.0f);
-        int current = -1, light_id = -1;
         f4 isec;
         isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
         float lim = 0.0f;
-        BvhRay br = bvh_ray_setup(probe, bv.max_abs_coord);
+        BvhRay br = bvh_ray_setup(h.probe, bv.max_abs_coord);
         for (;;) {
-            uint32_t nid = 0;
-            if (refill_take(gq, g_total, next, busy, nid)) {
-                id = nid;
-                const float4 a = b.s0[id], pr = b.p0[id], ls = b.p2[id];
-                const uint2 sc3 = b.s3[id];
-                probe.o = mk3(a.x, a.y, a.z);
-                probe.d = mk3(pr.x, pr.y, pr.z);
-                light_id = __float_as_int(pr.w);
+            uint32_t k = 0;
+            if (refill_take(g_total, next, busy, k)) {
+                i = last - k;
+                load_probe_head(b, i, h);
+                const float4 ls = b.p2[i];
                 isec.x = ls.x; isec.y = ls.y; isec.z = ls.z; isec.w = ls.w;
-                seed = sc3.x;
-                current = (int)(sc3.y & CURRENT_MASK);
-                kept_flags = sc3.y >> 30;
-                br = bvh_ray_setup(probe, bv.max_abs_coord);
+                br = bvh_ray_setup(h.probe, bv.max_abs_coord);
                 const bool bounded = isec.z >= 0.0f;       // a light was hit: only triangles not farther than it matter
                 const float t_light = isec.z / isec.w;
                 ok = br.finite && (!bounded || (t_light - t_light) == 0.0f);
@@ -611,9 +616,9 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh 
                 const Tri t = load_leaf_tri(bv, slot);
                 PlaneTest pt;
                 float rx, ry;
-                if (plane_test_closest(probe, t, isec, pt) && inside_test(probe, t, pt, rx, ry)) {
+                if (plane_test_closest(h.probe, t, isec, pt) && inside_test(h.probe, t, pt, rx, ry)) {
                     const int tid = leaf_tri_id(bv, slot);
-                    if (tid >= lights && tid != current) { blocked = true; return false; }
+                    if (tid >= lights && tid != h.current) { blocked = true; return false; }
                 }
                 return true;
             };
@@ -622,27 +627,17 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh 
             const bool fin = busy && !ts.run;
             const bool redo = fin && !ok && (lights < count);
             if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-                const bool b2 = closer_any_hit_range(sc.geo, lights, count, probe, isec, current, redo);
+                const bool b2 = closer_any_hit_range(sc.geo, lights, count, h.probe, isec, h.current, redo);
                 if (redo) blocked = b2;
             }
-            bool to_next = false;
+            PathState ps;
+            uint32_t kept_flags = 0;
+            bool go_on = false;
             if (fin) {
-                const int outcome = blocked ? 0 : (light_id < 0 ? 1 : 2);
-                PathState ps;
-                load_path(b, id, ps);
-                ps.seed = seed;
-                const float4 c = b.p1[id];
-                ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
-                if (outcome == 0 && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
-                to_next = finish_glossy(sc, fr, ps, current, outcome, probe.d, light_id, isec, mk3(c.x, c.y, c.z), c.w);
-                if (outcome != 0) {
-                    b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
-                    kept_flags |= KEPT_SPEC;
-                }
-                store_path(b, id, ps);
-                b.s3[id] = make_uint2(ps.seed, (uint32_t)current | (kept_flags << 30));
+                const int outcome = blocked ? 0 : (h.light_id < 0 ? 1 : 2);
+                go_on = retire_glossy(sc, fr, b, i, h, outcome, h.light_id, isec, ps, kept_flags) && deeper;
             }
-            region_push(b.q_ext[q_in ^ 1] + region, fill_next, to_next && deeper, id);
+            route_next(b, q_in ^ 1, fill_next, fin, go_on, ps, h.id, kept_flags);
             busy = busy && ts.run;
         }
         wstat_add(b, WSTAT_GLOSSY, g_total);
@@ -653,7 +648,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh 
 }
 
 // Extend stage for depth >= 1 with lane refill: the closest-hit search alone; it leaves the hit record
-// h0 = (u, v, t, triangle id; -1 = miss) and k_shade does the shading with full waves.
+// h0 = (u, v, t, triangle id; -1 = miss) beside each path record and k_shade does the shading with full waves.
 __global__ __launch_bounds__(64 * WG_WAVES) void k_extend_refill(DScene sc, DBvh bv, PipeBuffers b, int q_in) {
     const uint32_t lane = lane_index(), wave = wave_index();
     __shared__ int stack_mem[BVH_STACK * 64 * WG_WAVES];
@@ -665,8 +660,9 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend_refill(DScene sc, DBvh
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const uint32_t total = b.n_ext[q_in][wave];
-    const uint32_t *__restrict__ q = b.q_ext[q_in] + (size_t)wave * b.region_cap;
-    uint32_t next = 0, id = 0;
+    const size_t region = (size_t)wave * b.region_cap;
+    uint32_t next = 0;
+    size_t i = region;
     bool busy = false;
     TravState ts;
     ts.node = 0; ts.sp = 0; ts.run = false;
@@ -676,10 +672,10 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend_refill(DScene sc, DBvh
     ClosestFold cf;
     closest_fold_reset(cf, 1.0f);
     for (;;) {
-        uint32_t nid = 0;
-        if (refill_take(q, total, next, busy, nid)) {
-            id = nid;
-            const float4 a = b.s0[id], c = b.s1[id];
+        uint32_t k = 0;
+        if (refill_take(total, next, busy, k)) {
+            i = region + k;
+            const float4 a = b.xa[q_in][i], c = b.xb[q_in][i];
             ray.o = mk3(a.x, a.y, a.z);
             ray.d = mk3(a.w, c.x, c.y);
             br = bvh_ray_setup(ray, bv.max_abs_coord);
@@ -695,7 +691,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend_refill(DScene sc, DBvh
         closest_fold_redo(sc, ray, fin && (!br.finite || cf.n_near > 2), 0, sc.count, -1, 1.0f, cf);
         if (fin) {
             const float inv_det = 1.0f / cf.st.w;
-            b.h0[id] = make_float4(cf.st.x * inv_det, cf.st.y * inv_det, cf.st.z * inv_det, __int_as_float(cf.best));
+            b.h0[i] = make_float4(cf.st.x * inv_det, cf.st.y * inv_det, cf.st.z * inv_det, __int_as_float(cf.best));
         }
         busy = busy && ts.run;
     }
@@ -715,7 +711,7 @@ __global__ __launch_bounds__(256) void k_sum_counts(const uint32_t *__restrict__
     if (threadIdx.x == 0) *out = part[0] + part[1] + part[2] + part[3];
 }
 
-// Resolve stage: sum[pixel] += energy of the batch's samples, ascending slot order.
+// Resolve stage: sum[pixel] += radiance of the batch's samples, ascending slot order.
 __global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restrict__ sum, uint32_t width,
                                                  uint32_t height, uint32_t paths_per_sample, uint32_t n_slots) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -725,8 +721,8 @@ __global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restri
     const uint32_t local = ((ty >> 3) * tiles_x + (tx >> 3)) * 64u + (ty & 7u) * 8u + (tx & 7u);
     float4 s = sum[pix];
     for (uint32_t k = 0; k < n_slots; k++) {
-        const float4 e = b.s2[k * paths_per_sample + local];
-        s.x += e.y; s.y += e.z; s.z += e.w;
+        const float4 e = b.energy[(size_t)k * paths_per_sample + local];
+        s.x += e.x; s.y += e.y; s.z += e.z;
     }
     sum[pix] = s;
 }
@@ -746,14 +742,15 @@ struct Pipeline {
     // light seeds are also needed on the host to tabulate the per-depth coin; set before run()
     std::vector<uint32_t> h_light_seeds;
 
+    std::vector<void **> path_buffers() {
+        return {(void **)&buf.xa[0], (void **)&buf.xa[1], (void **)&buf.xb[0], (void **)&buf.xb[1], (void **)&buf.xc[0],
+                (void **)&buf.xc[1], (void **)&buf.xd[0], (void **)&buf.xd[1], (void **)&buf.pa, (void **)&buf.pb,
+                (void **)&buf.pc, (void **)&buf.pd, (void **)&buf.p0, (void **)&buf.p1, (void **)&buf.p2, (void **)&buf.h0,
+                (void **)&buf.energy, (void **)&buf.kd, (void **)&buf.ks};
+    }
+
     void free_paths() {
-        (void)hipFree(buf.s0); (void)hipFree(buf.s1); (void)hipFree(buf.s2); (void)hipFree(buf.s3);
-        (void)hipFree(buf.p0); (void)hipFree(buf.p1); (void)hipFree(buf.p2); (void)hipFree(buf.kd); (void)hipFree(buf.ks);
-        (void)hipFree(buf.h0);
-        (void)hipFree(buf.q_ext[0]); (void)hipFree(buf.q_ext[1]); (void)hipFree(buf.q_shadow); (void)hipFree(buf.q_glossy);
-        buf.s0 = buf.s1 = buf.s2 = buf.p0 = buf.p1 = buf.p2 = buf.kd = buf.ks = buf.h0 = nullptr;
-        buf.s3 = nullptr;
-        buf.q_ext[0] = buf.q_ext[1] = buf.q_shadow = buf.q_glossy = nullptr;
+        for (void **p : path_buffers()) { (void)hipFree(*p); *p = nullptr; }
         cap_paths = 0;
     }
 
@@ -792,21 +789,25 @@ struct Pipeline {
         }
         if (paths > cap_paths) {
             free_paths();
+            // queue planes hold PIPE_WAVES regions; h0 is indexed by path id at depth 0 and by queue position later
             const size_t qn = (size_t)region_cap_for(paths) * PIPE_WAVES;
-            PIPE_ALLOC(buf.s0, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.s1, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.s2, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.s3, sizeof(uint2) * paths);
-            PIPE_ALLOC(buf.p0, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.p1, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.p2, sizeof(float4) * paths);
+            for (int k = 0; k < 2; k++) {
+                PIPE_ALLOC(buf.xa[k], sizeof(float4) * qn);
+                PIPE_ALLOC(buf.xb[k], sizeof(float4) * qn);
+                PIPE_ALLOC(buf.xc[k], sizeof(float4) * qn);
+                PIPE_ALLOC(buf.xd[k], sizeof(uint4) * qn);
+            }
+            PIPE_ALLOC(buf.pa, sizeof(float4) * qn);
+            PIPE_ALLOC(buf.pb, sizeof(float4) * qn);
+            PIPE_ALLOC(buf.pc, sizeof(float4) * qn);
+            PIPE_ALLOC(buf.pd, sizeof(uint4) * qn);
+            PIPE_ALLOC(buf.p0, sizeof(float4) * qn);
+            PIPE_ALLOC(buf.p1, sizeof(float4) * qn);
+            PIPE_ALLOC(buf.p2, sizeof(float4) * qn);
+            PIPE_ALLOC(buf.h0, sizeof(float4) * qn);
+            PIPE_ALLOC(buf.energy, sizeof(float4) * paths);
             PIPE_ALLOC(buf.kd, sizeof(float4) * paths);
             PIPE_ALLOC(buf.ks, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.h0, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.q_ext[0], sizeof(uint32_t) * qn);
-            PIPE_ALLOC(buf.q_ext[1], sizeof(uint32_t) * qn);
-            PIPE_ALLOC(buf.q_shadow, sizeof(uint32_t) * qn);
-            PIPE_ALLOC(buf.q_glossy, sizeof(uint32_t) * qn);
             cap_paths = paths;
         }
         if (coins > cap_coins) {

@@ -164,13 +164,14 @@ int rt_reset_stats(rt_context *ctx);
 /* Tuning knobs; unknown names return RT_ERR_INVALID.
  *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
  *                   1 = staged kernels over compacted ray queues (default)
- *   "batch_samples" samples rendered per pass of the staged pipeline (default 16; 124 bytes of
+ *   "batch_samples" samples rendered per pass of the staged pipeline (default 16; about 320 bytes of
  *                   device memory per pixel and sample of a pass)
  *   "accel"         -1 = bounding-volume hierarchy for scenes of 64 triangles or more (default),
  *                   0 = the reference's loops over all triangles, 1 = hierarchy always; results are identical
  *   "fuse_shade"    1 = the closest-hit kernel also shades its paths (default), 0 = separate shade kernel
  *   "refill"        1 = traversal kernels hand finished lanes new rays (needs the hierarchy and fuse_shade = 1),
- *                   0 = every wave processes its queue in chunks of 64 (default)
+ *                   0 = every wave processes its queue in chunks of 64, -1 = by scene size (default: from 65536
+ *                   triangles on); results are identical
  *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
 int rt_set_option(rt_context *ctx, const char *name, int64_t value);
 
