@@ -49,7 +49,8 @@ struct DBvh {
 #endif
 constexpr int BVH_STACK = RT_BVH_STACK;
 constexpr float BVH_NEAR = 1.0f + 1.0f / 4096.0f;    // 2^-12 depth margin
-constexpr int BVH_TOP_NODES = 256;                   // nodes nearest the root that a workgroup keeps in LDS (16 KB)
+constexpr int BVH_TOP_NODES = 192;                   // nodes nearest the root that a workgroup keeps in LDS (12 KB)
+constexpr int BVH_LIGHT_TOP_NODES = 64;              // the same for the hierarchy over the emissive triangles (4 KB)
 
 // Per-lane traversal state that lives in LDS: this lane's column of a stack array [BVH_STACK][64], and the
 // workgroup's copy of the first n_top nodes of the hierarchy (breadth-first order, so these are the levels
@@ -63,8 +64,8 @@ struct BvhScratch {
 };
 
 // Cooperative copy of the top of the hierarchy into LDS; every thread of the workgroup calls it.
-RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top) {
-    const int n_top = bv.enabled ? (bv.n_nodes < BVH_TOP_NODES ? bv.n_nodes : BVH_TOP_NODES) : 0;
+RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top, int max_nodes = BVH_TOP_NODES) {
+    const int n_top = bv.enabled ? (bv.n_nodes < max_nodes ? bv.n_nodes : max_nodes) : 0;
     for (int i = threadIdx.x; i < n_top * 4; i += blockDim.x) top[i] = ((const v4f *)bv.nodes)[i];
     __syncthreads();
     return n_top;
@@ -328,13 +329,11 @@ RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
 }
 
 // sampleLightGlossy's search (raytracer.glsl:403-419) in its two-phase form, see glossy_search_bf.
-// `lbv` is a hierarchy over the light triangles [0, lights) alone; the LDS copy in `ws` belongs to `bv`.
+// `lbv` is a hierarchy over the light triangles [0, lights) alone; `ws` holds the LDS copy of `bv`, `lws` that of `lbv`.
 RT_DEV int glossy_search_bvh(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &ray, int current, bool active,
-                             int &light_id, f4 &isec, const BvhScratch &ws, BvhCounters &cnt) {
+                             int &light_id, f4 &isec, const BvhScratch &ws, const BvhScratch &lws, BvhCounters &cnt) {
     const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
     if (lbv.enabled) {
-        BvhScratch lws = ws;
-        lws.n_top = 0;
         light_id = closest_hit_bvh(sc, lbv, ray, active, 0, lights, current, 0.0f, lws, isec, cnt);
     } else {
         isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;

@@ -56,7 +56,11 @@ constexpr int PIPE_WAVES = 256 * RT_WAVES_PER_CU;    // persistent grid, all wav
 constexpr int WG_WAVES = RT_WG_WAVES;                // waves per workgroup: they share the LDS copy of the hierarchy's top
 static_assert(PIPE_WAVES % WG_WAVES == 0, "the grid is a whole number of workgroups");
 
-RT_DEV uint32_t wave_index() { return blockIdx.x * (uint32_t)WG_WAVES + (threadIdx.x >> 6); }
+// Wave-uniform by construction; readfirstlane tells the compiler so, which moves everything derived from it
+// (region bases, depth-0 tile coordinates) to the scalar unit.
+RT_DEV uint32_t wave_index() {
+    return blockIdx.x * (uint32_t)WG_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
 RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
 
 // Queues without atomics.  Every pipeline kernel runs exactly PIPE_WAVES waves (in workgroups of WG_WAVES), and
@@ -408,6 +412,10 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
     ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
     ws.top = (lds_v4f_ptr)top_mem;
     ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
+    __shared__ v4f light_top_mem[BVH ? BVH_LIGHT_TOP_NODES * 4 : 1];
+    BvhScratch lws = ws;
+    lws.top = (lds_v4f_ptr)light_top_mem;
+    lws.n_top = BVH ? bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES) : 0;
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const size_t region = (size_t)wave * b.region_cap;
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
         load_probe_head(b, i, h);
         int light_id;
         f4 lsec;
-        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, bc)
+        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, bc)
                                 : glossy_search_bf(sc, h.probe, h.current, live, light_id, lsec);
         PathState ps;
         uint32_t kept_flags = 0;
@@ -476,8 +484,10 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh 
     ws.stack = stack_mem + (threadIdx.x >> 6) * (BVH_STACK * 64) + lane;
     ws.top = (lds_v4f_ptr)top_mem;
     ws.n_top = bvh_stage_top(bv, top_mem);
+    __shared__ v4f light_top_mem[BVH_LIGHT_TOP_NODES * 4];
     BvhScratch lws = ws;
-    lws.n_top = 0;
+    lws.top = (lds_v4f_ptr)light_top_mem;
+    lws.n_top = bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const size_t region = (size_t)wave * b.region_cap;
