@@ -276,6 +276,112 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
     }
 }
 
+// Depth 0 in one kernel: camera ray, closest hit, shading, the bounce's light probe and the rest of the bounce.
+// At depth 0 the 64 lanes of a wave are the pixels of one 8x8 tile of one sample, so they all draw the same
+// coin (raytracer.glsl:553: light_seed depends on SAMPLE and depth only) and run the same kind of probe, from
+// neighbouring surface points: the probe can run in place with full lanes, and the probe records (112 bytes
+// per path written and read back) are never made.  Deeper bounces mix samples in a wave and keep the queues.
+template <bool BVH>
+__global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
+                                                         const uint32_t *__restrict__ samples,
+                                                         const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
+                                                         uint32_t n_slots, int max_depth) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    const uint32_t total = paths_per_sample * n_slots;
+    const uint32_t tiles_x = (fr.width + 7u) >> 3;
+    __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
+    __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
+    __shared__ v4f light_top_mem[BVH ? BVH_LIGHT_TOP_NODES * 4 : 1];
+    BvhScratch ws;
+    ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
+    ws.top = (lds_v4f_ptr)top_mem;
+    ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
+    BvhScratch lws = ws;
+    lws.top = (lds_v4f_ptr)light_top_mem;
+    lws.n_top = BVH ? bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES) : 0;
+    BvhCounters bc, pc;
+    bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
+    uint32_t n_paths = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
+    const bool deeper = 1 < max_depth;
+
+    for (uint32_t base = wave * 64u; base < total; base += (uint32_t)PIPE_WAVES * 64u) {
+        const uint32_t id = base + lane;
+        PathState ps;
+        const bool live = first_path(fr, samples, paths_per_sample, tiles_x, id, id < total, ps);
+        n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
+        Ray ray; ray.o = ps.o; ray.d = ps.d;
+        f4 isec;
+        const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, isec, bc)
+                            : closest_hit_bf(sc, ray, isec);
+        const float inv_det = 1.0f / isec.w;
+        // one coin for the whole wave: `base` lies in one sample's range of path ids
+        const bool coin_diffuse = coins[(base / paths_per_sample) * (uint32_t)max_depth] != 0u;
+        Bounce bn;
+        bn.kind = PROBE_NONE; bn.max_t = 0.0f; bn.w = 0.0f; bn.roughness = 0.0f;
+        bn.c = bn.lit = bn.albedo = bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
+        bool shaded = false;
+        if (live) {
+            if (hit < 0) {
+                ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
+            } else {
+                shade_pre(sc, fr, ps, hit, isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, coin_diffuse, bn);
+                shaded = true;
+            }
+        }
+        Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
+        ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
+        uint32_t kept_flags = 0;
+        bool go_on = false;
+        if (coin_diffuse) {
+            const bool run = shaded && bn.kind == PROBE_SHADOW;
+            bool blocked = true;
+            if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+                blocked = BVH ? shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run, ws, pc)
+                              : shadow_any_hit_bf(sc, probe, bn.max_t, hit, run);
+                n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
+            }
+            if (shaded) {
+                const bool written = run && !blocked;
+                if (written) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
+                go_on = finish_diffuse(sc, ps, hit, written, bn.lit, bn.albedo, bn.roughness) && deeper;
+            }
+        } else {
+            const bool run = shaded && bn.kind == PROBE_GLOSSY;
+            int outcome = 0, light_id = -1;
+            f4 lsec;
+            lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
+            if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+                outcome = BVH ? glossy_search_bvh(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, pc)
+                              : glossy_search_bf(sc, probe, hit, run, light_id, lsec);
+                n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
+            }
+            if (shaded) {
+                go_on = finish_glossy(sc, fr, ps, hit, run ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w) && deeper;
+                if (run && outcome != 0) {
+                    b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
+                    kept_flags |= KEPT_SPEC;
+                }
+            }
+        }
+        route_next(b, 1, fill_next, live, go_on, ps, id, kept_flags);
+    }
+    if (lane == 0) {
+        b.n_shadow[wave] = 0;
+        b.n_glossy[wave] = 0;
+        b.n_ext[1][wave] = fill_next;
+    }
+    wstat_add(b, WSTAT_PATHS, n_paths);
+    wstat_add(b, WSTAT_RAYS, n_paths);
+    wstat_add(b, WSTAT_SHADOW, n_shadow);
+    wstat_add(b, WSTAT_GLOSSY, n_glossy);
+    if (BVH) {
+        wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
+        wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
+        wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(pc.nodes));
+        wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(pc.tris));
+    }
+}
+
 // Shade stage of the unfused form.
 template <bool FIRST>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
@@ -934,6 +1040,17 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
 #define LAUNCH_EXTEND(F, FU, BV)                                                                                        \
     hipLaunchKernelGGL((k_extend<F, FU, BV>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples, d_coins, \
                        pps, (uint32_t)n, max_depth)
+        if (fused && depth == 0) {
+            // depth 0 runs its probes in place (k_first), so q_in = 0 is never read and the next queue is 1
+            if (use_bvh) hipLaunchKernelGGL(k_first<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins,
+                                            pps, (uint32_t)n, max_depth);
+            else hipLaunchKernelGGL(k_first<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins,
+                                    pps, (uint32_t)n, max_depth);
+            PIPE_TRY(hipGetLastError());
+            PIPE_TRY(stamp(-1));
+            q_in ^= 1;
+            continue;
+        }
         if (use_refill && depth > 0) {
             hipLaunchKernelGGL(k_extend_refill, grid, block, 0, stream, sc, bvh, buf, q_in);
             PIPE_TRY(hipGetLastError());
