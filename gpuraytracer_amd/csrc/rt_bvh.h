@@ -92,20 +92,18 @@ RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
 }
 
 // Slab test against a box widened by r (one fused multiply-add per plane; this test only has to be
-// conservative, it takes no part in the hit arithmetic).  Returns the entry distance (clamped at 0) or a
-// negative value when the box is missed or lies beyond `t_max`.  min/max ignore NaN (inf - inf for a ray
-// parallel to a slab), which errs on the side of visiting.
-RT_DEV float box_entry(const BvhRay &br, f3 lo, f3 hi, float t_max) {
+// conservative, it takes no part in the hit arithmetic).  Gives the entry distance (clamped at 0) and the exit
+// distance (clamped at `t_max`); the box is entered within t_max iff t_in <= t_out.  min/max ignore NaN
+// (inf - inf for a ray parallel to a slab), which errs on the side of visiting.  The rounding of these
+// operations (a few 2^-24 of |origin| * |inv|) is below 1/16 of the widening r * |inv| = 2^-16 * |origin| * |inv|.
+RT_DEV void box_slabs(const BvhRay &br, f3 lo, f3 hi, float t_max, float &t_in, float &t_out) {
     const float ax = __builtin_fmaf(lo.x, br.inv.x, -br.oi_hi.x), bx = __builtin_fmaf(hi.x, br.inv.x, -br.oi_lo.x);
     const float ay = __builtin_fmaf(lo.y, br.inv.y, -br.oi_hi.y), by = __builtin_fmaf(hi.y, br.inv.y, -br.oi_lo.y);
     const float az = __builtin_fmaf(lo.z, br.inv.z, -br.oi_hi.z), bz = __builtin_fmaf(hi.z, br.inv.z, -br.oi_lo.z);
-    float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
-                               __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-    float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
-                               __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
-    // widen the exit side for the rounding of the slab arithmetic itself
-    t1 = t1 * 1.0000004f;
-    return (t0 <= t1) ? t0 : -1.0f;
+    t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                           __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+    t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                            __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
 }
 
 struct BvhCounters { uint32_t nodes, tris; };
@@ -134,34 +132,39 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const BvhScratch &ws, 
     for (;;) {
         const unsigned long long running = __builtin_amdgcn_ballot_w64(run);
         if (running == 0ull || 64 - (int)__popcll(running) >= stop_at) break;
-        while (__builtin_amdgcn_ballot_w64(run && node >= 0) != 0ull) {
-            if (run && node >= 0) {
-                v4f q0, q1, q2, q3;
-                if (node < ws.n_top) {
-                    q0 = ws.top[4 * node + 0]; q1 = ws.top[4 * node + 1]; q2 = ws.top[4 * node + 2]; q3 = ws.top[4 * node + 3];
-                } else {
-                    const v4f *g = (const v4f *)bv.nodes;
-                    q0 = g[4 * node + 0]; q1 = g[4 * node + 1]; q2 = g[4 * node + 2]; q3 = g[4 * node + 3];
-                }
-                cnt.nodes++;
-                const float lim = t_limit();
-                const float e0 = box_entry(br, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), lim);
-                const float e1 = box_entry(br, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), lim);
-                const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                const bool h0 = e0 >= 0.0f, h1 = e1 >= 0.0f;
-                const bool both = h0 & h1, none = !(h0 | h1);
-                const bool first0 = e0 <= e1;
-                // the child to descend into: the nearer one of two, or the only one entered
-                const int near = (both ? first0 : h0) ? c0 : c1;
-                if (both) stack[64 * sp] = first0 ? c1 : c0;
-                sp += both ? 1 : 0;
-                const bool pop = none & (sp > 0);
-                sp -= pop ? 1 : 0;
-                int next = near;
-                if (pop) next = stack[64 * sp];
-                run = !none | pop;
-                node = next;
+        // a divergent loop: lanes leave as they reach a leaf or finish, and the wave goes on when none is left
+        while (run && node >= 0) {
+            v4f q0, q1, q2, q3;
+            if (node < ws.n_top) {
+                q0 = ws.top[4 * node + 0]; q1 = ws.top[4 * node + 1]; q2 = ws.top[4 * node + 2]; q3 = ws.top[4 * node + 3];
+            } else {
+                const v4f *g = (const v4f *)bv.nodes;
+                q0 = g[4 * node + 0]; q1 = g[4 * node + 1]; q2 = g[4 * node + 2]; q3 = g[4 * node + 3];
             }
+            cnt.nodes++;
+            const float lim = t_limit();
+            float in0, out0, in1, out1;
+            box_slabs(br, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), lim, in0, out0);
+            box_slabs(br, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), lim, in1, out1);
+            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            // the decisions as wave masks: their combinations then cost scalar instructions, and each
+            // per-lane choice a single select
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(in0 <= out0);
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(in1 <= out1);
+            const unsigned long long first0 = __builtin_amdgcn_ballot_w64(in0 <= in1);
+            const unsigned long long both_m = m0 & m1, any_m = m0 | m1;
+            const bool both = __builtin_amdgcn_inverse_ballot_w64(both_m);
+            // the child to descend into: the nearer one of two, or the only one entered
+            const int near = __builtin_amdgcn_inverse_ballot_w64(m0 & (first0 | ~m1)) ? c0 : c1;
+            if (both) stack[64 * sp] = __builtin_amdgcn_inverse_ballot_w64(first0) ? c1 : c0;
+            sp += both ? 1 : 0;
+            const unsigned long long pop_m = __builtin_amdgcn_ballot_w64(sp > 0) & ~any_m;
+            const bool pop = __builtin_amdgcn_inverse_ballot_w64(pop_m);
+            sp -= pop ? 1 : 0;
+            int next = near;
+            if (pop) next = stack[64 * sp];
+            run = __builtin_amdgcn_inverse_ballot_w64(any_m | pop_m);
+            node = next;
         }
         if (run) {      // node < 0: a leaf
             const int code = ~node;
