@@ -33,7 +33,9 @@ sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
 # FP32 vector rate without fused multiply-add: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (one flop per lane
-# and issue slot); half of the 157.3 TFLOP/s FMA figure.  The intersection arithmetic may not contract.
+# and clock); half of the 157.3 TFLOP/s FMA figure.  The intersection arithmetic may not contract.  Reaching
+# this rate takes packed instructions (two flops per lane and issue slot); plain wave64 instructions sustain
+# one per 4 clocks and SIMD, half of it (tools/microbench_valu.hip).
 PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 FLOPS_PER_CLOSEST_TEST = 35     # raytracer.glsl:135-158, full pass
 FLOPS_PER_PROBE_TEST = 34       # raytracer.glsl:171-195
@@ -83,14 +85,14 @@ def load_workload(g, args):
     return scene, cam, 6, "synthetic height field %d tris, %d^2 atlas on 2 materials" % (len(scene[0]), args.atlas), layers
 
 
-def measured_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter pass of this command
-    (FETCH_SIZE and WRITE_SIZE, separate runs; FETCH_SIZE doubled as gfx950 reports half of wide reads)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def profile_counters(kernel_key):
+    """Per-launch counters of one kernel from the committed rocprofv3 passes over this command (separate --pmc
+    runs, tools/prof_bench.sh): FETCH_SIZE_KB (to be doubled: gfx950 reports half of wide reads), WRITE_SIZE_KB,
+    vector instructions and vector-unit busy fraction."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
     try:
         with open(path) as f:
-            t = json.load(f)[kernel_key]
-        return 2.0 * t["FETCH_SIZE_KB"] * 1024.0 + t["WRITE_SIZE_KB"] * 1024.0
+            return json.load(f)[kernel_key]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -207,23 +209,35 @@ def main():
         ext_ms, ext_n = st["extend0_ms"], max(1, st["extend0_launches"])
         used_bvh = st["bvh_extend_nodes"] > 0
         if used_bvh:
-            # Hierarchy traversal: nodes and triangles come from L1/L2 (the scene is 60 KB); what has to cross
-            # HBM is the path state the stage leaves behind: ray/throughput/radiance 48 B + seed/triangle 8 B +
-            # probe record 32 B + queue entry 4 B per camera path.
-            bytes_per_path = 92.0
-            algo = float(st["pixel_samples"]) * bytes_per_path
+            # Depth-0 kernel (camera ray, closest hit by hierarchy, shading, light probe in place, rest of the
+            # bounce).  Nodes and triangles come from LDS/L1/L2; what has to cross HBM is what the stage leaves
+            # behind: a 16-byte radiance record per path that ended, a 64-byte path record per path that goes on.
+            d1 = float(st["depth1_paths"])
+            algo = (float(st["pixel_samples"]) - d1) * 16.0 + d1 * 64.0
             achieved = algo / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": "k_extend<FIRST,FUSED,BVH> (depth-0 closest hit by hierarchy + shading)",
+            prof = profile_counters("k_first<true>") if args.workload == "cubes" else None
+            roof = {"bound": "hbm", "kernel": "k_first<BVH> (depth 0: camera ray, closest hit by hierarchy, shading, "
+                                              "light probe in place, rest of the bounce)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": measured_traffic("k_extend<true, true, true>") if args.workload == "cubes" else None,
+                    "traffic": (2.0 * prof["FETCH_SIZE_KB"] + prof["WRITE_SIZE_KB"]) * 1024.0 if prof else None,
                     "bytes_per_launch": algo / ext_n,
-                    "note": "instruction-issue bound (SIMDs ~80 % busy), not bandwidth bound: see profiles/"}
+                    "note": "bound by vector instruction issue, not by bandwidth: see valu_issue"}
+            if prof and ext_ms > 0:
+                # vector instructions of one launch (committed counter pass of this command) over the live launch time,
+                # against the sustained issue rate of wave64 vector instructions without packed math
+                # (tools/microbench_valu.hip: one per 4 clocks and SIMD; 1024 SIMDs at 2.4 GHz)
+                peak = 1024 * 2.4e9 / 4.0 / 1e9
+                rate = prof["valu_wave_insts"] / (ext_ms / ext_n * 1e-3) / 1e9
+                roof["valu_issue"] = {"bound": "valu", "achieved": rate, "peak": peak, "unit": "G wave-instructions/s",
+                                      "frac": rate / peak, "counter_busy_frac": prof["valu_busy_frac"],
+                                      "wave_insts_per_launch": prof["valu_wave_insts"]}
         else:
             flops = float(st["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
             achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
-            roof = {"bound": "valu", "kernel": "k_extend<FIRST,FUSED> (depth-0 loop over all triangles + shading)",
+            roof = {"bound": "valu", "kernel": "k_first<false> (depth 0 with loops over all triangles)",
                     "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None, "flops_per_launch": flops / ext_n}
+                    "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None, "flops_per_launch": flops / ext_n,
+                    "note": "closest-hit tests only; the launch also runs the probe loops of depth 0"}
         roof.update({"avg_launch_ms": ext_ms / ext_n, "launches": int(st["extend0_launches"]),
                      "probe_kernels_ms": st["probe_ms"], "extend_kernels_ms": st["extend_ms"],
                      "shade_kernels_ms": st["shade_ms"]})
@@ -253,9 +267,12 @@ def main():
             "roofline": roof,
         }
         if world == 1 and used_bvh and not args.no_bruteforce_pass and args.workload == "cubes":
-            # the reference's own algorithm (loop over all COUNT triangles per query) on the same GPU, short pass
+            # the reference's own algorithm (loops over all COUNT triangles per query) on the same GPU: a short
+            # pass of depth 0 alone (RECURSION 1), so that every closest-hit loop and every probe loop runs in the
+            # one kernel that is timed
             ctx.set_option("accel", 0)
             ctx.set_option("batch_samples", 4)
+            ctx.set_frame(cam, clock, 1, 1.0)
             sums.zero_()
             ctx.reset_stats()
             torch.cuda.synchronize()
@@ -264,14 +281,19 @@ def main():
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
             s1 = ctx.stats()
-            f1 = float(s1["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
+            n_tri = len(scene[0])
+            f1 = (float(s1["pixel_samples"]) * n_tri * FLOPS_PER_CLOSEST_TEST
+                  + float(s1["shadow_probes"] + s1["glossy_probes"]) * (n_tri - 1) * FLOPS_PER_PROBE_TEST)
             a1 = f1 / (s1["extend0_ms"] * 1e-3) / 1e12 if s1["extend0_ms"] > 0 else 0.0
             out["roofline_bruteforce"] = {
-                "bound": "valu", "kernel": "k_extend<FIRST,FUSED> (depth-0 loop over all 424 triangles + shading)",
+                "bound": "valu", "kernel": "k_first<false> (depth 0 with loops over all %d triangles: closest hit, "
+                                           "shading, light probe)" % n_tri,
                 "achieved": a1, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": a1 / PEAK_VALU_TFLOPS,
                 "avg_launch_ms": s1["extend0_ms"] / max(1, s1["extend0_launches"]),
                 "flops_per_launch": f1 / max(1, s1["extend0_launches"]),
-                "value_Mrays_per_s": s1["rays"] / dt1 / 1e6, "sample": "64 spp"}
+                "value_Mrays_per_s": s1["rays"] / dt1 / 1e6, "sample": "64 spp, RECURSION 1",
+                "note": "flops counted as full tests; triangles whose plane test fails for the whole wave skip the "
+                        "rest, and plain (unpacked) instructions sustain half of the peak"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, clock, RECURSION)
         print(json.dumps(out))

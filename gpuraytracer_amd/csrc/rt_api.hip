@@ -653,7 +653,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     }
     DStats ds;
     HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
-    unsigned long long ws[8];
+    unsigned long long ws[WSTAT_SLOTS];
     HIP_TRY(ctx, ctx->pipe.read_wstats(ws));
     ds.pixel_samples += ws[WSTAT_PATHS];
     ds.rays += ws[WSTAT_RAYS];
@@ -674,6 +674,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     s.bvh_extend_tris = ds.ext_tris;
     s.bvh_probe_nodes = ds.probe_nodes;
     s.bvh_probe_tris = ds.probe_tris;
+    s.depth1_paths = ws[WSTAT_DEPTH1];
     *out = s;
     return RT_OK;
 }

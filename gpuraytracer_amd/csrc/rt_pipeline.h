@@ -77,12 +77,12 @@ struct PipeBuffers {
     float4 *h0, *energy, *kd, *ks;
     uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
     uint32_t region_cap;
-    unsigned long long *wstats;                 // [PIPE_WAVES][8] per-wave work counters (see WSTAT_*)
+    unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
     uint32_t *total;                            // scratch word for the early-stop read-back
 };
 
 enum { WSTAT_PATHS = 0, WSTAT_RAYS, WSTAT_SHADOW, WSTAT_GLOSSY, WSTAT_EXT_NODES, WSTAT_EXT_TRIS, WSTAT_PROBE_NODES,
-       WSTAT_PROBE_TRIS };
+       WSTAT_PROBE_TRIS, WSTAT_DEPTH1, WSTAT_SLOTS = 16 };
 
 constexpr uint32_t KEPT_DIFF = 1u, KEPT_SPEC = 2u;      // kept flags
 constexpr uint32_t CURRENT_MASK = 0x3FFFFFFFu;
@@ -131,7 +131,7 @@ RT_DEV void route_next(const PipeBuffers &b, int q_out, uint32_t &fill_next, boo
 }
 
 RT_DEV void wstat_add(const PipeBuffers &b, int which, unsigned long long v) {
-    if (lane_index() == 0 && v) b.wstats[(size_t)wave_index() * 8 + which] += v;
+    if (lane_index() == 0 && v) b.wstats[(size_t)wave_index() * WSTAT_SLOTS + which] += v;
 }
 
 struct RouteFill { uint32_t shadow, glossy, next; };
@@ -304,7 +304,17 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
     uint32_t n_paths = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
     const bool deeper = 1 < max_depth;
 
+#if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS > 0
+    unsigned long long clk[4] = {0, 0, 0, 0};
+#define SECTION_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); clk[k] += now_ - mark_; mark_ = now_; } while (0)
+#else
+#define SECTION_MARK(k) do { } while (0)
+#define RT_SECTION_CLOCKS 0
+#endif
     for (uint32_t base = wave * 64u; base < total; base += (uint32_t)PIPE_WAVES * 64u) {
+#if RT_SECTION_CLOCKS > 0
+        unsigned long long mark_ = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t id = base + lane;
         PathState ps;
         const bool live = first_path(fr, samples, paths_per_sample, tiles_x, id, id < total, ps);
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
         f4 isec;
         const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, isec, bc)
                             : closest_hit_bf(sc, ray, isec);
+        SECTION_MARK(0);
         const float inv_det = 1.0f / isec.w;
         // one coin for the whole wave: `base` lies in one sample's range of path ids
         const bool coin_diffuse = coins[(base / paths_per_sample) * (uint32_t)max_depth] != 0u;
@@ -328,6 +339,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
                 shaded = true;
             }
         }
+        SECTION_MARK(1);
         Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
         ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
         uint32_t kept_flags = 0;
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
                               : shadow_any_hit_bf(sc, probe, bn.max_t, hit, run);
                 n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             }
+            SECTION_MARK(2);
             if (shaded) {
                 const bool written = run && !blocked;
                 if (written) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
@@ -355,6 +368,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
                               : glossy_search_bf(sc, probe, hit, run, light_id, lsec);
                 n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             }
+            SECTION_MARK(RT_SECTION_CLOCKS == 2 ? 3 : 2);     // 2: the glossy probe is booked on the last slot
             if (shaded) {
                 go_on = finish_glossy(sc, fr, ps, hit, run ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w) && deeper;
                 if (run && outcome != 0) {
@@ -364,6 +378,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
             }
         }
         route_next(b, 1, fill_next, live, go_on, ps, id, kept_flags);
+        SECTION_MARK(3);
     }
     if (lane == 0) {
         b.n_shadow[wave] = 0;
@@ -372,14 +387,24 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
     }
     wstat_add(b, WSTAT_PATHS, n_paths);
     wstat_add(b, WSTAT_RAYS, n_paths);
+    wstat_add(b, WSTAT_DEPTH1, fill_next);
     wstat_add(b, WSTAT_SHADOW, n_shadow);
     wstat_add(b, WSTAT_GLOSSY, n_glossy);
+#if RT_SECTION_CLOCKS > 0
+    // measurement build: the four hierarchy counters carry the cycles of the four sections instead
+    wstat_add(b, WSTAT_EXT_NODES, clk[0]);
+    wstat_add(b, WSTAT_EXT_TRIS, clk[1]);
+    wstat_add(b, WSTAT_PROBE_NODES, clk[2]);
+    wstat_add(b, WSTAT_PROBE_TRIS, clk[3]);
+#else
     if (BVH) {
         wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
         wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(pc.nodes));
         wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(pc.tris));
     }
+#endif
+#undef SECTION_MARK
 }
 
 // Shade stage of the unfused form.
@@ -893,9 +918,9 @@ struct Pipeline {
         hipError_t e = hipSuccess;
 #define PIPE_ALLOC(ptr, bytes) do { *what = #ptr; e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
         if (!buf.wstats) {
-            PIPE_ALLOC(buf.wstats, sizeof(unsigned long long) * 8 * PIPE_WAVES);
+            PIPE_ALLOC(buf.wstats, sizeof(unsigned long long) * WSTAT_SLOTS * PIPE_WAVES);
             *what = "memset wstats";
-            e = hipMemset(buf.wstats, 0, sizeof(unsigned long long) * 8 * PIPE_WAVES);
+            e = hipMemset(buf.wstats, 0, sizeof(unsigned long long) * WSTAT_SLOTS * PIPE_WAVES);
             if (e != hipSuccess) return e;
             PIPE_ALLOC(buf.n_ext[0], sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_ext[1], sizeof(uint32_t) * PIPE_WAVES);
@@ -969,19 +994,19 @@ struct Pipeline {
         return e;
     }
 
-    // Sums the per-wave work counters into `out` (8 values, WSTAT_* order); synchronous.
-    hipError_t read_wstats(unsigned long long out[8]) {
-        for (int k = 0; k < 8; k++) out[k] = 0;
+    // Sums the per-wave work counters into `out` (WSTAT_SLOTS values, WSTAT_* order); synchronous.
+    hipError_t read_wstats(unsigned long long out[WSTAT_SLOTS]) {
+        for (int k = 0; k < WSTAT_SLOTS; k++) out[k] = 0;
         if (!buf.wstats) return hipSuccess;
-        std::vector<unsigned long long> h((size_t)8 * PIPE_WAVES);
+        std::vector<unsigned long long> h((size_t)WSTAT_SLOTS * PIPE_WAVES);
         hipError_t e = hipMemcpy(h.data(), buf.wstats, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
         if (e != hipSuccess) return e;
-        for (size_t i = 0; i < h.size(); i++) out[i & 7] += h[i];
+        for (size_t i = 0; i < h.size(); i++) out[i % WSTAT_SLOTS] += h[i];
         return hipSuccess;
     }
     hipError_t reset_wstats(hipStream_t stream) {
         if (!buf.wstats) return hipSuccess;
-        return hipMemsetAsync(buf.wstats, 0, sizeof(unsigned long long) * 8 * PIPE_WAVES, stream);
+        return hipMemsetAsync(buf.wstats, 0, sizeof(unsigned long long) * WSTAT_SLOTS * PIPE_WAVES, stream);
     }
 
     // Renders the `n` samples listed in d_samples and adds them to `sum`.

@@ -77,6 +77,7 @@ typedef struct rt_stats {
     uint64_t extend0_launches;
     /* hierarchy traversal (option "accel"): node visits and triangle tests actually executed */
     uint64_t bvh_extend_nodes, bvh_extend_tris, bvh_probe_nodes, bvh_probe_tris;
+    uint64_t depth1_paths;      /* camera paths that went on to a second bounce (staged form with fused depth 0; else 0) */
 } rt_stats;
 
 typedef struct rt_context rt_context;

@@ -1,5 +1,5 @@
 """Summarises the CSV files a tools/prof_bench.sh run left in gpurun_out/prof_<tag>/: kernel stats, per-kernel
-averages of every counter, and (third argument) a JSON with the per-launch HBM traffic and SIMD occupancy of
+averages of every counter, and (third argument) a JSON with the per-launch HBM traffic and vector-unit occupancy of
 each kernel for bench.py.     python tools/prof_summary.py <tag> [summary.txt [traffic.json]]"""
 import collections, csv, glob, json, sys
 
@@ -40,10 +40,14 @@ if len(sys.argv) > 3:
             e["FETCH_SIZE_KB"] = c["FETCH_SIZE"]
         if "WRITE_SIZE" in c:
             e["WRITE_SIZE_KB"] = c["WRITE_SIZE"]
-        if "SQ_ACTIVE_INST_ANY" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
-            # SQ_ACTIVE_INST_ANY counts quad-cycles summed over waves; GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
-            e["simd_issue_busy_frac"] = c["SQ_ACTIVE_INST_ANY"] * 4.0 / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
-            if "SQ_ACTIVE_INST_VALU" in c:
-                e["simd_valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles (4 clocks) summed over waves; a wave64 vector instruction
+            # without packed math occupies its SIMD for one of them (tools/microbench_valu.hip: 4.2-4.7 clocks
+            # per instruction and SIMD sustained).  GRBM_GUI_ACTIVE sums the 8 XCDs; the chip has 1024 SIMDs.
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+            e["gpu_cycles"] = cycles
+            e["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024.0)
+            if "SQ_INSTS_VALU" in c:
+                e["valu_wave_insts"] = c["SQ_INSTS_VALU"]
         js[k.replace("rt::", "")] = e
     json.dump(js, open(sys.argv[3], "w"), indent=1, sort_keys=True)

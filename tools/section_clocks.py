@@ -1,0 +1,31 @@
+"""Cycle split of the depth-0 kernel (library built with -DRT_SECTION_CLOCKS): with RECURSION 1 only k_first
+runs, and the four hierarchy counters carry the cycles its waves spent in
+  closest hit (camera ray + traversal) | shading before the probe | light probe | rest of the bounce + routing.
+Usage: GPURT_LIB=.../libgpurt_clk.so python tools/section_clocks.py [cubes|obiwan]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gpuraytracer_amd as g
+import bench
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cubes"
+scene = g.read_rtscene(os.path.join(bench.ROOT, "tests", "golden", "scenes", {"cubes": "cubes", "obiwan": "_ObiWan"}[name] + ".rtscene"))
+ctx = g.Context(0)
+ctx.set_option("profiling", 1)
+ctx.upload_scene(*scene)
+ctx.upload_env(bench.constant_env())
+ctx.resize(bench.W, bench.H)
+sums = torch.zeros(bench.H * bench.W * 4, dtype=torch.float32, device="cuda")
+ctx.set_sum_buffer(sums.data_ptr())
+ctx.set_frame(g.camera_matrix(), g.DEFAULT_CLOCK, 1, 1.0)
+ctx.trace(0, 32, 1)
+torch.cuda.synchronize()
+ctx.reset_stats()
+ctx.trace(32, 64, 1)
+torch.cuda.synchronize()
+st = ctx.stats()
+c = np.array([st["bvh_extend_nodes"], st["bvh_extend_tris"], st["bvh_probe_nodes"], st["bvh_probe_tris"]], dtype=np.float64)
+print(name, "paths", st["pixel_samples"], "probes", st["shadow_probes"] + st["glossy_probes"], "k_first ms", st["extend0_ms"])
+for label, v in zip(("closest hit", "shade_pre", "probe", "finish+route"), c):
+    print("  %-13s %5.1f %%   %.0f cycles per wave-tile" % (label, 100 * v / c.sum(), v / (st["pixel_samples"] / 64)))
