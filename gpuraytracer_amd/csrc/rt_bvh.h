@@ -107,6 +107,17 @@ RT_DEV void box_slabs(const BvhRay &br, f3 lo, f3 hi, float t_max, float &t_in, 
 }
 
 struct BvhCounters { uint32_t nodes, tris; };
+// Normal builds count the node visits and triangle tests of every lane.  With -DRT_COUNT_WAVE_STEPS the first
+// active lane adds 64 per step instead, i.e. the lane slots the wave spent: the ratio of the two builds'
+// numbers is the lane utilisation of the traversal loops.
+#ifdef RT_COUNT_WAVE_STEPS
+RT_DEV uint32_t bvh_count_step() {
+    const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u)) == 0u ? 64u : 0u;
+}
+#else
+RT_DEV uint32_t bvh_count_step() { return 1u; }
+#endif
 
 // Traversal state of one lane; it survives between calls of bvh_advance, so that a wave can hand finished
 // lanes new rays while the others are still under way.
@@ -141,7 +152,7 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const BvhScratch &ws, 
                 const v4f *g = (const v4f *)bv.nodes;
                 q0 = g[4 * node + 0]; q1 = g[4 * node + 1]; q2 = g[4 * node + 2]; q3 = g[4 * node + 3];
             }
-            cnt.nodes++;
+            cnt.nodes += bvh_count_step();
             const float lim = t_limit();
             float in0, out0, in1, out1;
             box_slabs(br, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), lim, in0, out0);
@@ -171,7 +182,7 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const BvhScratch &ws, 
             const int first = code >> 3, n = code & 7;
             bool go_on = true;
             for (int k = 0; k < n; k++) {
-                cnt.tris++;
+                cnt.tris += bvh_count_step();
                 if (go_on) go_on = leaf(first + k);
             }
             if (go_on && sp > 0) {
