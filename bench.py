@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--grid", type=int, default=724, help="c3: cells per side of the height field")
     ap.add_argument("--atlas", type=int, default=1024, help="c3: edge of the texture layers")
     ap.add_argument("--refill", type=int, default=-1, help="-1 library default, 0/1 traversal kernels without/with lane refill")
+    ap.add_argument("--pool", type=int, default=-1, help="-1 library default, 0/1 depth 0 without/with the workgroup probe pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
@@ -142,6 +143,8 @@ def main():
     ctx.set_option("accel", args.accel)
     if args.refill >= 0:
         ctx.set_option("refill", args.refill)
+    if args.pool >= 0:
+        ctx.set_option("pool", args.pool)
     ctx.set_option("profiling", 1)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)

@@ -173,6 +173,9 @@ int rt_reset_stats(rt_context *ctx);
  *   "refill"        1 = traversal kernels hand finished lanes new rays (needs the hierarchy and fuse_shade = 1),
  *                   0 = every wave processes its queue in chunks of 64, -1 = by scene size (default: from 65536
  *                   triangles on); results are identical
+ *   "pool"          1 = at depth 0 the waves of a workgroup pool their light probes and draw dense packets from
+ *                   the pool (needs the hierarchy and fuse_shade = 1), 0 = every lane runs its own probe
+ *                   (default, faster); results are identical
  *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
 int rt_set_option(rt_context *ctx, const char *name, int64_t value);
 
