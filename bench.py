@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): the reference's bundled `cubes` scene (424 triangles, 24 of
+Workload (the configuration the headline metric is quoted on): the reference's bundled `cubes` scene (424 triangles, 24 of
 them emissive), 1920x1080, RECURSION 6, CLOCK 95834783, default camera, constant environment
 (the reference's .exr environment is not in its repository; data is synthetic in that sense).
 One step renders `--spp-per-step` samples per pixel (64 by default); the default 16 steps are the

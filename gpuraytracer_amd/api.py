@@ -14,7 +14,7 @@ MATERIAL_DTYPE = np.dtype([("albedo", "<f4", 4), ("specular_roughness", "<f4", 4
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_synchronize", "rt_upload_scene",
-    "rt_set_atlas_size", "rt_upload_atlas_layer", "rt_set_has_texture", "rt_upload_env", "rt_resize",
+    "rt_set_atlas_size", "rt_upload_atlas_layer", "rt_set_has_texture", "rt_upload_env", "rt_prefilter_irradiance", "rt_resize",
     "rt_set_sum_buffer", "rt_set_frame", "rt_trace", "rt_read_sum", "rt_closest_hit_batch",
     "rt_closest_hit_batch_device", "rt_read_srgb8", "rt_get_stats", "rt_reset_stats", "rt_set_option",
 ]
@@ -67,6 +67,7 @@ def load_library():
     lib.rt_upload_atlas_layer.argtypes = [vp, c.c_uint32, c.c_uint32, c.c_uint32, c.c_uint32, vp]
     lib.rt_set_has_texture.argtypes = [vp, vp, c.c_uint32]
     lib.rt_upload_env.argtypes = [vp, c.c_uint32, c.c_uint32, vp]
+    lib.rt_prefilter_irradiance.argtypes = [vp, vp, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     lib.rt_resize.argtypes = [vp, c.c_uint32, c.c_uint32]
     lib.rt_set_sum_buffer.argtypes = [vp, vp]
     lib.rt_set_frame.argtypes = [vp, vp, c.c_uint32, c.c_int32, c.c_float]
@@ -158,6 +159,14 @@ class Context:
         if rgba.ndim != 3 or rgba.shape[2] != 4:
             raise ValueError("rgba must be [h, w, 4]")
         self._check(self.lib.rt_upload_env(self.h, rgba.shape[1], rgba.shape[0], _ptr(rgba)))
+
+    def prefilter_irradiance(self):
+        """Scene.cpp:150-186: the (h//4, w//4, 3) irradiance image of the uploaded environment."""
+        w, h = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        self._check(self.lib.rt_prefilter_irradiance(self.h, None, ctypes.byref(w), ctypes.byref(h)))
+        out = np.zeros((h.value, w.value, 3), dtype=np.float32)
+        self._check(self.lib.rt_prefilter_irradiance(self.h, _ptr(out), ctypes.byref(w), ctypes.byref(h)))
+        return out
 
     def resize(self, width, height):
         self._check(self.lib.rt_resize(self.h, width, height))

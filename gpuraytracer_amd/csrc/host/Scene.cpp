@@ -205,7 +205,23 @@ bool Scene::loadEnvironmentTexture(const std::string &texture_name) {
         return false;
     }
     std::cout << texture_name << '\t' << w << 'x' << h << std::endl;
-    return setEnvironment((uint32_t)w, (uint32_t)h, rgba.data());
+    if (!setEnvironment((uint32_t)w, (uint32_t)h, rgba.data())) return false;
+    // Scene.cpp:163-199: "<name>-irradiance.exr" is used if present, otherwise computed and written.  The path
+    // tracer never samples it, so a file that is present is left alone here.
+    const std::string irr_name = texture_name + "-irradiance.exr";
+    int iw = 0, ih = 0;
+    std::vector<float> have;
+    if (!readEXR(irr_name, iw, ih, have, &err)) {
+        uint32_t ow = 0, oh = 0;
+        if (rt_prefilter_irradiance(m_ctx, nullptr, &ow, &oh) != RT_OK) return false;
+        std::vector<float> rgb((size_t)ow * oh * 3);
+        if (ow && oh) {
+            if (rt_prefilter_irradiance(m_ctx, rgb.data(), &ow, &oh) != RT_OK) return false;
+            if (!writeEXR(irr_name, (int)ow, (int)oh, 3, rgb.data(), &err))
+                std::cerr << "Save EXR err: " << err << std::endl;           // Scene.cpp:195-198: reported, not fatal
+        }
+    }
+    return true;
 }
 
 bool Scene::setEnvironment(uint32_t w, uint32_t h, const float *rgba) {

@@ -18,6 +18,7 @@
 #include "rt_kernels.h"
 #include "rt_pipeline.h"
 #include "rt_bvh_build.h"
+#include "rt_irradiance.h"
 
 using namespace rt;
 
@@ -432,6 +433,29 @@ int rt_upload_env(rt_context *ctx, uint32_t w, uint32_t h, const float *rgba) {
     HIP_TRY(ctx, hipMemcpy(ctx->d_env, rgba, sizeof(float4) * (size_t)w * h, hipMemcpyHostToDevice));
     ctx->env_w = (int)w;
     ctx->env_h = (int)h;
+    return RT_OK;
+}
+
+int rt_prefilter_irradiance(rt_context *ctx, float *rgb, uint32_t *out_w, uint32_t *out_h) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->d_env) return fail(ctx, RT_ERR_INVALID, "rt_prefilter_irradiance: no environment uploaded");
+    const uint32_t w = (uint32_t)ctx->env_w, h = (uint32_t)ctx->env_h, iw = w / 4u, ih = h / 4u;
+    if (out_w) *out_w = iw;
+    if (out_h) *out_h = ih;
+    if (!rgb) return RT_OK;                   // size query
+    if (iw == 0 || ih == 0) return RT_OK;     // as in the reference: an image of no texels
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    const size_t n = (size_t)iw * ih;
+    float4 *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_out, sizeof(float4) * n));
+    hipLaunchKernelGGL(k_irradiance, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, ctx->d_env, w, h, d_out);
+    hipError_t e = hipGetLastError();
+    std::vector<float4> host(n);
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out, sizeof(float4) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "rt_prefilter_irradiance: %s", hipGetErrorString(e));
+    for (size_t i = 0; i < n; i++) { rgb[3 * i] = host[i].x; rgb[3 * i + 1] = host[i].y; rgb[3 * i + 2] = host[i].z; }
     return RT_OK;
 }
 

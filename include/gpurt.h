@@ -119,6 +119,13 @@ int rt_set_has_texture(rt_context *ctx, const int32_t *flags, uint32_t n);
 /* Scene::loadEnvironmentTexture (Scene.cpp:104-160): RGBA32F, bilinear, repeat. */
 int rt_upload_env(rt_context *ctx, uint32_t w, uint32_t h, const float *rgba);
 
+/* The irradiance pre-filter Scene::loadEnvironmentTexture runs when no "<name>-irradiance.exr" exists
+ * (Scene.cpp:150-186 with res/shader/irradiance.glsl:20-39): from the uploaded w x h environment to an
+ * (w/4) x (h/4) RGB float image, row 0 first, as the reference reads it back for SaveEXR (Scene.cpp:188-199).
+ * `rgb` may be NULL to query the size only.  The path tracer itself never samples this image
+ * (skyColorDiffuse, raytracer.glsl:277-280, has no caller); it exists for hosts that write the file. */
+int rt_prefilter_irradiance(rt_context *ctx, float *rgb, uint32_t *out_w, uint32_t *out_h);
+
 /* Scene::adaptResolution (Scene.cpp:397-421): (re)allocate the accumulation target
  * and clear it.  The target holds per-pixel SUMS of sample radiance, not the
  * reference's running mean, so that partial results from several launches or

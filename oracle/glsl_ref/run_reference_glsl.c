@@ -101,7 +101,7 @@ static struct scene load_scene(const char *path) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s image|hits|probe ...\n", argv[0]); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: %s image|hits|func|pack|irradiance|probe ...\n", argv[0]); return 1; }
     setenv("GALLIUM_DRIVER", "llvmpipe", 0);
     void *drv = dlopen("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so", RTLD_NOW | RTLD_GLOBAL);
     if (!drv) { fprintf(stderr, "dlopen driver: %s\n", dlerror()); return 10; }
@@ -241,6 +241,57 @@ int main(int argc, char **argv) {
         fwrite(out, 4, n_items * per, f);
         fclose(f);
         fprintf(stderr, "func: %zu items, gl error 0x%x\n", n_items, glGetError());
+        return 0;
+    }
+
+    if (!strcmp(argv[1], "irradiance")) {
+        /* irradiance <env.f32> <w> <h> <out.f32>: the pre-filter of Scene::loadEnvironmentTexture (Scene.cpp:150-186)
+         * with the reference's res/shader/irradiance.glsl, unmodified: radiance image w x h on image unit 0, irradiance
+         * image (w/4) x (h/4) on unit 1, one dispatch per radiance row (uniform 1 = row), ((w/4) >> 6) + 1 by h/4
+         * workgroups (what the reference's ceilPower2 evaluates to), read back as RGB float.  The reference starts
+         * from freshly allocated texture storage; here the irradiance image is explicitly zero-filled. */
+        const int w = atoi(argv[3]), h = atoi(argv[4]);
+        size_t got;
+        char *env = read_file(argv[2], &got);
+        if (got < 16ul * w * h) { fprintf(stderr, "environment file too short\n"); return 2; }
+        char *text = read_file("/root/reference/res/shader/irradiance.glsl", NULL);
+        GLuint sh = glCreateShader(GL_COMPUTE_SHADER);
+        const char *srcs[1] = {text};
+        glShaderSource(sh, 1, srcs, NULL);
+        glCompileShader(sh);
+        GLint ok = 0;
+        glGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
+        if (!ok) { char log[8192]; glGetShaderInfoLog(sh, sizeof(log), NULL, log); fprintf(stderr, "compile failed:\n%s\n", log); return 21; }
+        GLuint prog = glCreateProgram();
+        glAttachShader(prog, sh);
+        glLinkProgram(prog);
+        glGetProgramiv(prog, GL_LINK_STATUS, &ok);
+        if (!ok) { char log[8192]; glGetProgramInfoLog(prog, sizeof(log), NULL, log); fprintf(stderr, "link failed:\n%s\n", log); return 22; }
+        glUseProgram(prog);
+        const int iw = w / 4, ih = h / 4;
+        GLuint tex[2];
+        glGenTextures(2, tex);
+        glBindTexture(GL_TEXTURE_2D, tex[0]);
+        glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA32F, w, h);
+        glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, w, h, GL_RGBA, GL_FLOAT, env);
+        glBindTexture(GL_TEXTURE_2D, tex[1]);
+        glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA32F, iw, ih);
+        float *zero = (float *)calloc((size_t)iw * ih * 4, 4);
+        glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, iw, ih, GL_RGBA, GL_FLOAT, zero);
+        glBindImageTexture(0, tex[0], 0, GL_FALSE, 0, GL_READ_ONLY, GL_RGBA32F);
+        glBindImageTexture(1, tex[1], 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA32F);
+        for (int row = 0; row < h; row++) {
+            glUniform1i(1, row);
+            glDispatchCompute((GLuint)((iw >> 6) + 1), (GLuint)ih, 1);
+            glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT);
+        }
+        glFinish();
+        float *out = (float *)malloc((size_t)iw * ih * 12);
+        glGetTexImage(GL_TEXTURE_2D, 0, GL_RGB, GL_FLOAT, out);
+        FILE *f = fopen(argv[5], "wb");
+        fwrite(out, 12, (size_t)iw * ih, f);
+        fclose(f);
+        fprintf(stderr, "irradiance: %dx%d -> %dx%d, gl error 0x%x\n", w, h, iw, ih, glGetError());
         return 0;
     }
 

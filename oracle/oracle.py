@@ -40,6 +40,7 @@ def _load(libm):
     lib.orc_math.argtypes = [c.c_int, c.c_float, c.c_float]
     lib.orc_math_batch.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_uint64, c.c_void_p]
     lib.orc_sample_env.argtypes = [c.c_void_p, c.c_void_p, c.c_uint64, c.c_void_p]
+    lib.orc_irradiance.argtypes = [c.c_void_p, c.c_uint32, c.c_uint32, c.c_void_p]
     lib.orc_scene_create.restype = c.c_void_p
     lib.orc_scene_create.argtypes = [c.c_void_p, c.c_void_p, c.c_uint32, c.c_uint32, c.c_void_p, c.c_uint32]
     lib.orc_scene_destroy.argtypes = [c.c_void_p]
@@ -88,6 +89,15 @@ _MATH_CODES = {"sin": 0, "cos": 1, "tan": 2, "acos": 3, "asin": 4, "atan2": 5, "
 
 def math_fn(which, x, y=0.0, libm=False):
     return np.float32(_load(libm).orc_math(_MATH_CODES[which], ctypes.c_float(x), ctypes.c_float(y)))
+
+
+def irradiance(env_rgba, libm=False):
+    """Irradiance pre-filter (Scene.cpp:150-186 + irradiance.glsl): RGBA float32 (h, w, 4) in, RGB (h//4, w//4, 3) out."""
+    env = np.ascontiguousarray(env_rgba, dtype=np.float32)
+    h, w = env.shape[:2]
+    out = np.zeros((h // 4, w // 4, 3), dtype=np.float32)
+    _load(libm).orc_irradiance(_ptr(env), w, h, _ptr(out))
+    return out
 
 
 def math_batch(which, x, y=None, libm=False):

@@ -682,6 +682,43 @@ void orc_sample_env(const void *h, const float *st, uint64_t n, float *rgb) {
     }
 }
 
+// Irradiance pre-filter of the environment map: Scene::loadEnvironmentTexture (Scene.cpp:150-186) runs
+// irradiance.glsl once per radiance row; every texel of the (w/4) x (h/4) irradiance image accumulates, in row
+// order and left to right within a row, weight * radiance with weight = max(uvDotUV(uv, UV), 0) * 2 / (w * h)
+// (irradiance.glsl:16-18, :27-38).  uv = (i, row) / size and UV = 4 * texel / size are corner coordinates, as in
+// the reference.  Mesa: products left to right; no fused multiply-add.
+void orc_irradiance(const float *env_rgba, uint32_t w, uint32_t h, float *out_rgb) {
+    const float PI = 3.141592653589793f, TWO_PI = 2.0f * PI;
+    const uint32_t iw = w / 4, ih = h / 4;
+    const float isx = 1.0f / (float)w, isy = 1.0f / (float)h;
+    const float renorm = (2.0f / (float)w) / (float)h;     // Mesa: these two divisions stay divisions
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t t = 0; t < (int64_t)iw * ih; t++) {
+        const uint32_t X = (uint32_t)(t % iw), Y = (uint32_t)(t / iw);
+        const float Ux = ((float)X * isx) * 4.0f, Uy = ((float)Y * isy) * 4.0f;
+        float sU, cU;
+        m_sincos(PI * Uy, sU, cU);
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        for (uint32_t row = 0; row < h; row++) {
+            const float uy = (float)row * isy;
+            float sy, cy;
+            m_sincos(PI * uy, sy, cy);
+            const float polar = cy * cU;
+            for (uint32_t i = 0; i < w; i++) {
+                const float ux = (float)i * isx;
+                float s_, c;
+                m_sincos(TWO_PI * (ux - Ux), s_, c);
+                const float weight = gmax(polar + (c * sy) * sU, 0.0f) * renorm;
+                const float *px = env_rgba + 4 * ((size_t)row * w + i);
+                r = r + weight * px[0];
+                g = g + weight * px[1];
+                b = b + weight * px[2];
+            }
+        }
+        out_rgb[3 * t] = r; out_rgb[3 * t + 1] = g; out_rgb[3 * t + 2] = b;
+    }
+}
+
 void *orc_scene_create(const void *models, const void *shadings, uint32_t count, uint32_t lights,
                        const void *materials, uint32_t n_materials) {
     Scene *sc = new Scene();

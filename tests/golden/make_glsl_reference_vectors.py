@@ -14,6 +14,9 @@ Writes tests/golden/ref_*.npz; nothing of the reference's text is stored, only i
   ref_image_<case>.npz   the image the reference's main() writes for single SAMPLE values on a cleared target
                      (for SAMPLE = S > 0 that is colour * 1/(S+1), raytracer.glsl:609-613), and for the
                      cubes case also the running mean over SAMPLE 0..15
+  ref_irradiance.npz the (w/4) x (h/4) image the reference's res/shader/irradiance.glsl leaves after one dispatch
+                     per radiance row (Scene.cpp:150-186), for three small random environments
+                     (`python tests/golden/make_glsl_reference_vectors.py irradiance` makes this file alone)
   ref_c1_cubes512.json   the reference's own CPU-runnable configuration (cubes, 512 x 512, SAMPLE 0..15): SHA-256
                      of the RGB float32 bytes of each single-SAMPLE image and of the 16-sample running mean
                      (results are compared bit for bit, so a digest is enough), and llvmpipe's wall time
@@ -86,6 +89,26 @@ def ref_image(scene, env, width, height, clock, recursion, first, count, cam, at
         args.append(atlas)
     run(*args)
     return np.fromfile(tmp("img.f32"), dtype=np.float32).reshape(height, width, 4)[..., :3].copy()
+
+
+def ref_irradiance(env):
+    h, w = env.shape[:2]
+    np.ascontiguousarray(env, dtype=np.float32).tofile(tmp("irr_env.f32"))
+    run("irradiance", tmp("irr_env.f32"), w, h, tmp("irr_out.f32"))
+    return np.fromfile(tmp("irr_out.f32"), dtype=np.float32).reshape(h // 4, w // 4, 3)
+
+
+def make_irradiance():
+    os.makedirs(TMP, exist_ok=True)
+    out = {}
+    for k, (w, h, seed) in enumerate(((64, 32, 5), (52, 28, 6), (100, 50, 7))):
+        rng = np.random.default_rng(seed)
+        env = rng.random((h, w, 4), dtype=np.float32) * 3.0
+        env[..., 3] = 1.0
+        out["env%d" % k] = env
+        out["irr%d" % k] = ref_irradiance(env)
+        print("irradiance %dx%d -> %dx%d" % (w, h, w // 4, h // 4))
+    np.savez_compressed(os.path.join(HERE, "ref_irradiance.npz"), **out)
 
 
 def write_atlas(path, size, uploads, flags):
@@ -182,6 +205,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_image_cubes_textured.npz"), **out)
     print("image cubes_textured         48x32 RECURSION 6 SAMPLE [0, 1, 2, 3]")
 
+    make_irradiance()
+
     # --- the reference's CPU-runnable configuration, as digests
     cam = camera_matrix()
     env = constant_env()
@@ -204,4 +229,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["irradiance"]:
+        make_irradiance()
+    else:
+        main()

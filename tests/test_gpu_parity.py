@@ -270,6 +270,25 @@ def test_textured_materials_bit_exact(gpu_ctx, oracle_mod):
     gpu_ctx.set_atlas_size(4096)
 
 
+def test_irradiance_prefilter_bit_exact(gpu_ctx, oracle_mod):
+    # Scene.cpp:150-186 + irradiance.glsl against the reference shader's own output, and a larger case against the oracle
+    g = np.load(os.path.join(GOLDEN, "ref_irradiance.npz"))
+    for k in range(3):
+        gpu_ctx.upload_env(g["env%d" % k])
+        got = gpu_ctx.prefilter_irradiance()
+        assert got.shape == g["irr%d" % k].shape
+        assert (got.view(np.uint32) == g["irr%d" % k].view(np.uint32)).all(), k
+    rng = np.random.default_rng(11)
+    env = rng.random((96, 200, 4), dtype=np.float32) * 5.0
+    gpu_ctx.upload_env(env)
+    got = gpu_ctx.prefilter_irradiance()
+    want = oracle_mod.irradiance(env)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    # an environment narrower than 4 texels has an empty irradiance image
+    gpu_ctx.upload_env(np.ones((2, 3, 4), dtype=np.float32))
+    assert gpu_ctx.prefilter_irradiance().shape == (0, 0, 3)
+
+
 def test_srgb8_readback(gpu_ctx, oracle_mod, cubes):
     _upload(gpu_ctx, cubes, constant_env())
     img, _ = _render(gpu_ctx, 32, 32, 0, 4)

@@ -119,6 +119,19 @@ def test_packed_float_upload_equals_gl(oracle_mod):
     assert same_bits(got, want).all()
 
 
+def test_irradiance_prefilter_equals_reference_shader(oracle_mod):
+    # the image the reference's irradiance.glsl leaves after one dispatch per radiance row (Scene.cpp:150-186);
+    # power-of-two and other sizes, the last with w/4 and h/4 rounded down
+    g = np.load(os.path.join(GOLDEN, "ref_irradiance.npz"))
+    for k in range(3):
+        got = oracle_mod.irradiance(g["env%d" % k])
+        assert got.shape == g["irr%d" % k].shape
+        assert same_bits(got, g["irr%d" % k]).all(), k
+    # the C-library back end differs in the cosines only
+    other = oracle_mod.irradiance(g["env1"], libm=True)
+    assert np.allclose(other, g["irr1"], rtol=1e-5, atol=0)
+
+
 def test_textured_images_equal_reference_shader(oracle_mod):
     # atlas path: texture coordinates, tangent frame, normal map, ARM layer, 11/11/10-bit texels
     from conftest import textured_cubes
