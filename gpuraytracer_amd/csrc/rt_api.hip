@@ -62,6 +62,7 @@ struct rt_context {
     int batch_samples = 16;
     int profiling = 0;
     int fuse_shade = 1;
+    int tonemap = 0;           // rt_read_srgb8: 0 sRGB transfer (displayQuad.fs), 1 ACES film curve first (Scene::exportBMP)
     int pool = 0;              // 1: depth 0 with the probes of a workgroup pooled (k_first_pool); slower, see there
     int refill = -1;           // -1 auto (lane refill from REFILL_AUTO_MIN triangles on), 0 off, 1 on
 
@@ -609,7 +610,7 @@ int rt_read_srgb8(rt_context *ctx, uint8_t *rgb) {
     unsigned char *d_out = nullptr;
     HIP_TRY(ctx, hipMalloc(&d_out, 3 * n));
     hipLaunchKernelGGL(k_srgb8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_sum,
-                       1.0f / (float)ctx->n_samples, n, d_out);
+                       1.0f / (float)ctx->n_samples, n, ctx->tonemap, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_out, 3 * n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -733,6 +734,9 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
         ctx->fuse_shade = value ? 1 : 0;
     } else if (!strcmp(name, "refill")) {
         ctx->refill = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (!strcmp(name, "tonemap")) {
+        if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "tonemap must be 0 or 1");
+        ctx->tonemap = (int)value;
     } else if (!strcmp(name, "pool")) {
         ctx->pool = value ? 1 : 0;
     } else if (!strcmp(name, "profiling")) {

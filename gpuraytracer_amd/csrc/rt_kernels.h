@@ -229,8 +229,10 @@ __global__ __launch_bounds__(256) void k_closest_hit_batch(DScene sc, const floa
     }
 }
 
-// sRGB transfer of the mean image, displayQuad.fs:19-34.
-__global__ void k_srgb8(const float4 *__restrict__ sum, float inv_n, unsigned long long n_pixels,
+// 8-bit output of the mean image.  aces = 0: the display path, displayQuad.fs:19-34 (sRGB transfer, rounded to
+// the nearest code).  aces = 1: the file path of Scene::exportBMP, Scene.cpp:564-567: ACESFilm (Scene.cpp:66-73),
+// then the sRGB transfer (Scene.cpp:58-64), then clamp(v * 256, 0, 255) truncated.
+__global__ void k_srgb8(const float4 *__restrict__ sum, float inv_n, unsigned long long n_pixels, int aces,
                         unsigned char *__restrict__ out) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
@@ -238,8 +240,13 @@ __global__ void k_srgb8(const float4 *__restrict__ sum, float inv_n, unsigned lo
     const float c[3] = {s.x * inv_n, s.y * inv_n, s.z * inv_n};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float v = (c[k] <= 0.0031308f) ? c[k] * 12.92f : 1.055f * __powf(c[k], 1.0f / 2.4f) - 0.055f;
-        v = v * 255.0f + 0.5f;
+        float x = c[k];
+        if (aces) {
+            x = (x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f);
+            x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+        }
+        float v = (x <= 0.0031308f) ? x * 12.92f : 1.055f * __powf(x, 1.0f / 2.4f) - 0.055f;
+        v = aces ? v * 256.0f : v * 255.0f + 0.5f;
         v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
         out[i * 3 + k] = (unsigned char)v;
     }

@@ -163,7 +163,9 @@ int rt_closest_hit_batch(rt_context *ctx, const float *o_xyz, const float *d_xyz
 int rt_closest_hit_batch_device(rt_context *ctx, const float *o_xyz, const float *d_xyz,
                                 uint64_t n, int32_t *id, float *uvt);
 
-/* displayQuad.fs:19-34: sRGB transfer of sum / n_samples to 8-bit RGB (row order as rt_read_sum). */
+/* displayQuad.fs:19-34: sRGB transfer of sum / n_samples to 8-bit RGB (row order as rt_read_sum).  With option
+ * "tonemap" = 1: the mapping of Scene::exportBMP instead (Scene.cpp:564-567: ACESFilm, sRGB transfer, v * 256
+ * truncated), still in RGB order. */
 int rt_read_srgb8(rt_context *ctx, uint8_t *rgb);
 
 int rt_get_stats(rt_context *ctx, rt_stats *out);
@@ -183,6 +185,7 @@ int rt_reset_stats(rt_context *ctx);
  *   "pool"          1 = at depth 0 the waves of a workgroup pool their light probes and draw dense packets from
  *                   the pool (needs the hierarchy and fuse_shade = 1), 0 = every lane runs its own probe
  *                   (default, faster); results are identical
+ *   "tonemap"       what rt_read_srgb8 applies: 0 = sRGB transfer (default), 1 = ACES film curve + sRGB transfer
  *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
 int rt_set_option(rt_context *ctx, const char *name, int64_t value);
 

@@ -297,6 +297,16 @@ def test_srgb8_readback(gpu_ctx, oracle_mod, cubes):
     want = np.vectorize(oracle_mod.linear_to_srgb)(mean.astype(np.float64)).astype(np.float64)
     want8 = np.clip(np.floor(want * 255.0 + 0.5), 0, 255)
     assert np.abs(rgb8.astype(np.int32) - want8.astype(np.int32)).max() <= 1     # displayQuad.fs:19-25, +-1 code
+    # the file mapping of Scene::exportBMP (Scene.cpp:66-73, :564-567): ACES film curve, sRGB transfer, * 256 truncated
+    gpu_ctx.set_option("tonemap", 1)
+    aces8 = gpu_ctx.read_srgb8()
+    gpu_ctx.set_option("tonemap", 0)
+    x = mean.astype(np.float64)
+    film = np.clip((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0.0, 1.0)
+    want = np.vectorize(oracle_mod.linear_to_srgb)(film)
+    want8 = np.clip(np.floor(want * 256.0), 0, 255)
+    assert np.abs(aces8.astype(np.int32) - want8.astype(np.int32)).max() <= 1
+    assert (aces8 != rgb8).any()
 
 
 def test_error_behaviour(oracle_mod, cubes):
