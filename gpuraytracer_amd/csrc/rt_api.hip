@@ -530,7 +530,17 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
     const DScene sc = device_scene(ctx);
 
     // samples are processed in chunks so that the per-launch tables stay small
-    const uint32_t chunk_max = ctx->pipeline == 0 ? 1024u : (uint32_t)(ctx->batch_samples > 0 ? ctx->batch_samples : 1);
+    uint32_t chunk_max = ctx->pipeline == 0 ? 1024u : (uint32_t)(ctx->batch_samples > 0 ? ctx->batch_samples : 1);
+    if (ctx->pipeline != 0) {
+        // the queues of a pass take about 320 bytes per pixel-sample: fewer samples per pass if that does not fit
+        // (the image does not depend on the batch size)
+        const size_t pps = (size_t)(((ctx->width + 7u) >> 3) * ((ctx->height + 7u) >> 3)) * 64u;
+        size_t free_b = 0, total_b = 0;
+        if (pps * chunk_max > ctx->pipe.cap_paths && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t have = ctx->pipe.cap_paths * 320u;       // released before the larger allocation is made
+            while (chunk_max > 1u && (double)pps * chunk_max * 320.0 > 0.9 * (double)(free_b + have)) chunk_max = (chunk_max + 1u) / 2u;
+        }
+    }
     int rc = ensure_sample_tables(ctx, chunk_max);
     if (rc) return rc;
     std::vector<uint32_t> samples(chunk_max), seeds(chunk_max);
