@@ -6,6 +6,8 @@
 // loops.  Here a bounce is split into stages that each run as their own kernel over densely
 // packed queues:
 //
+//   first    depth 0 in one kernel: camera ray, closest hit, shading, the probe in place (all lanes of a wave
+//            want the same kind of probe there), rest of the bounce                   -> extend queue of depth 1
 //   extend   closest hit (findIntersection) + everything of the bounce up to the probe loop;
 //            paths that need a probe go to the shadow or the glossy queue, paths that need none
 //            are finished (roulette) and go to the next extend queue
