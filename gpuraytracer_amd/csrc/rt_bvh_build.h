@@ -52,7 +52,10 @@ struct Item { Box box; float c[3]; int32_t id; };
 #define RT_MAX_LEAF 4
 #endif
 constexpr int MAX_LEAF = RT_MAX_LEAF;
-constexpr int BINS = 16;
+#ifndef RT_BVH_BINS
+#define RT_BVH_BINS 32
+#endif
+constexpr int BINS = RT_BVH_BINS;
 
 }  // namespace bvh_detail
 
