@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--atlas", type=int, default=1024, help="c3: edge of the texture layers")
     ap.add_argument("--refill", type=int, default=-1, help="-1 library default, 0/1 traversal kernels without/with lane refill")
     ap.add_argument("--pool", type=int, default=-1, help="-1 library default, 0/1 depth 0 without/with the workgroup probe pool")
+    ap.add_argument("--first-in-place", type=int, default=-1, help="-1 library default, 0/1 depth 0 through the queues / in one kernel")
+    ap.add_argument("--lane-utilisation", action="store_true",
+                    help="cubes/obiwan: add the lane utilisation of the traversal loops (two extra 32 spp renders in child processes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
@@ -145,6 +148,8 @@ def main():
         ctx.set_option("refill", args.refill)
     if args.pool >= 0:
         ctx.set_option("pool", args.pool)
+    if args.first_in_place >= 0:
+        ctx.set_option("first_in_place", args.first_in_place)
     ctx.set_option("profiling", 1)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
@@ -297,6 +302,10 @@ def main():
                 "value_Mrays_per_s": s1["rays"] / dt1 / 1e6, "sample": "64 spp, RECURSION 1",
                 "note": "flops counted as full tests; triangles whose plane test fails for the whole wave skip the "
                         "rest, and plain (unpacked) instructions sustain half of the peak"}
+        if args.lane_utilisation and world == 1 and args.workload in ("cubes", "obiwan"):
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import lane_utilisation
+            out["lane_utilisation"] = lane_utilisation.measure(args.workload, RECURSION)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, clock, RECURSION)
         print(json.dumps(out))

@@ -62,6 +62,7 @@ struct rt_context {
     int batch_samples = 16;
     int profiling = 0;
     int fuse_shade = 1;
+    int first_in_place = 1;    // depth 0 in one kernel with the probes in place (k_first); 0: depth 0 through the queues
     int tonemap = 0;           // rt_read_srgb8: 0 sRGB transfer (displayQuad.fs), 1 ACES film curve first (Scene::exportBMP)
     int pool = 0;              // 1: depth 0 with the probes of a workgroup pooled (k_first_pool); slower, see there
     int refill = -1;           // -1 auto (lane refill from REFILL_AUTO_MIN triangles on), 0 off, 1 on
@@ -569,7 +570,7 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
                                          ctx->d_sum, ctx->d_samples, (int)n, ctx->stream, ctx->profiling != 0,
                                          ctx->fuse_shade != 0,
                                          ctx->refill < 0 ? ctx->count >= REFILL_AUTO_MIN : ctx->refill != 0,
-                                         ctx->pool != 0,
+                                         ctx->pool != 0, ctx->first_in_place != 0,
                                          &ctx->host_stats, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
@@ -747,6 +748,8 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "tonemap")) {
         if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "tonemap must be 0 or 1");
         ctx->tonemap = (int)value;
+    } else if (!strcmp(name, "first_in_place")) {
+        ctx->first_in_place = value ? 1 : 0;
     } else if (!strcmp(name, "pool")) {
         ctx->pool = value ? 1 : 0;
     } else if (!strcmp(name, "profiling")) {

@@ -1285,12 +1285,12 @@ struct Pipeline {
     // Renders the `n` samples listed in d_samples and adds them to `sum`.
     hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                    const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                   bool pool, rt_stats *host_stats, const char **what);
+                   bool pool, bool in_place, rt_stats *host_stats, const char **what);
 };
 
 inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                                 const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                                bool pool, rt_stats *host_stats, const char **what) {
+                                bool pool, bool in_place, rt_stats *host_stats, const char **what) {
     const bool use_bvh = bvh.enabled != 0;
     // lane refill needs the hierarchy; it shades depth >= 1 in a kernel of its own
     const bool use_refill = use_bvh && refill && fused;
@@ -1338,7 +1338,7 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
 #define LAUNCH_EXTEND(F, FU, BV)                                                                                        \
     hipLaunchKernelGGL((k_extend<F, FU, BV>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples, d_coins, \
                        pps, (uint32_t)n, max_depth)
-        if (fused && depth == 0) {
+        if (fused && in_place && depth == 0) {
             // depth 0 runs its probes in place (k_first), so q_in = 0 is never read and the next queue is 1
             if (use_bvh && pool && buf.region_cap >= POOL_MIN_REGION)
                 hipLaunchKernelGGL(k_first_pool, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins, pps,

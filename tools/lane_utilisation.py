@@ -1,9 +1,14 @@
-"""Lane utilisation of the traversal loops: runs the same frames with the normal library and with one built
-with -DRT_COUNT_WAVE_STEPS (GPURT_LIB_WAVE_STEPS) in two child processes and divides the counters.
+"""Lane utilisation of the traversal loops: renders the same frames with the product library and with the variant
+built with -DRT_COUNT_WAVE_STEPS (gpuraytracer_amd/libgpurt_wavesteps.so; its traversal counters count the lane
+slots a wave spends), each in a child process, and divides the counters.
 Usage: python tools/lane_utilisation.py [cubes|obiwan] [recursion]"""
-import json, os, subprocess, sys
+import json
+import os
+import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANT = os.path.join(ROOT, "gpuraytracer_amd", "libgpurt_wavesteps.so")
 CHILD = r'''
 import os, sys, json
 sys.path.insert(0, %r)
@@ -19,18 +24,31 @@ ctx.trace(0, 32, 1); torch.cuda.synchronize()
 print(json.dumps(ctx.stats()))
 ''' % ROOT
 
-def run(lib, name, rec):
+
+def _run(lib, name, rec):
     env = dict(os.environ)
     if lib:
         env["GPURT_LIB"] = lib
-    return json.loads(subprocess.run([sys.executable, "-c", CHILD, name, str(rec)], env=env, check=True,
-                                     capture_output=True, text=True).stdout.strip().splitlines()[-1])
+    out = subprocess.run([sys.executable, "-c", CHILD, name, str(rec)], env=env, check=True, capture_output=True, text=True)
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
-name = sys.argv[1] if len(sys.argv) > 1 else "cubes"
-rec = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-a = run(None, name, rec)
-b = run(os.environ.get("GPURT_LIB_WAVE_STEPS", os.path.join(ROOT, "gpuraytracer_amd", "libgpurt_ws.so")), name, rec)
-print(name, "RECURSION", rec, "rays", a["rays"], "probes", a["shadow_probes"] + a["glossy_probes"])
-for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris"):
-    unit = a["rays"] if "extend" in k else a["shadow_probes"] + a["glossy_probes"]
-    print("  %-17s per query %6.2f   lane slots per query %6.2f   utilisation %.2f" % (k, a[k] / unit, b[k] / unit, a[k] / max(1, b[k])))
+
+def measure(name, recursion):
+    """{counter: (steps per query, lane slots per query, utilisation)} for 32 spp at 1080p."""
+    a = _run(None, name, recursion)
+    b = _run(os.environ.get("GPURT_LIB_WAVE_STEPS", VARIANT), name, recursion)
+    res = {"rays": a["rays"], "probes": a["shadow_probes"] + a["glossy_probes"]}
+    for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris"):
+        unit = max(1, a["rays"] if "extend" in k else res["probes"])
+        res[k] = {"per_query": a[k] / unit, "lane_slots_per_query": b[k] / unit, "utilisation": a[k] / max(1, b[k])}
+    return res
+
+
+if __name__ == "__main__":
+    name = sys.argv[1] if len(sys.argv) > 1 else "cubes"
+    rec = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    r = measure(name, rec)
+    print(name, "RECURSION", rec, "rays", r["rays"], "probes", r["probes"])
+    for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris"):
+        print("  %-17s per query %6.2f   lane slots per query %6.2f   utilisation %.2f"
+              % (k, r[k]["per_query"], r[k]["lane_slots_per_query"], r[k]["utilisation"]))
