@@ -857,7 +857,10 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
 // lanes carry on where they were (bvh_advance keeps per-lane traversal state).  A path's arithmetic does
 // not depend on which lane or in which order it is processed, and the order of a queue region only
 // decides the order of the next region, so results stay bit-identical.
-constexpr int REFILL_MIN = 24;
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 24
+#endif
+constexpr int REFILL_MIN = RT_REFILL_MIN;
 
 // Hands queue positions to the lanes that are not busy, once at least REFILL_MIN lanes are free.  Returns
 // true for the lanes that received one (in `k`).
