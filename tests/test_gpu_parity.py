@@ -194,6 +194,25 @@ def test_image_vs_checker_gradient_env_ragged(gpu_ctx, oracle_mod, cubes, pipeli
     assert np.sqrt(np.mean((img - ref) ** 2)) / np.mean(ref) < 0.02
 
 
+def test_full_size_forms_agree(gpu_ctx, oracle_mod, cubes):
+    # At the size of the headline measurement (1920 x 1080): the staged pipeline (hierarchy, batches of 3 and of 8
+    # samples) and the single kernel that loops over all triangles give the same sums bit for bit and the same
+    # counters over 8 samples, and one whole sample agrees with the checker bit for bit.
+    _upload(gpu_ctx, cubes, constant_env())
+    a, sa = _render(gpu_ctx, 1920, 1080, 0, 8, pipeline=1, batch=3)
+    b, sb = _render(gpu_ctx, 1920, 1080, 0, 8, pipeline=0)
+    c, sc_ = _render(gpu_ctx, 1920, 1080, 0, 8, pipeline=1, batch=8)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    for k in ("pixel_samples", "rays", "shadow_probes", "glossy_probes"):
+        assert sa[k] == sb[k] == sc_[k], k
+    assert sa["pixel_samples"] == 1920 * 1080 * 8
+    sc = oracle_mod.OracleScene(*cubes)
+    sc.upload_env(constant_env())
+    want, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 1920, 1080, 0, 1)
+    one, _ = _render(gpu_ctx, 1920, 1080, 0, 1)
+    assert np.array_equal(one, want)
+
+
 def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
     # glass (Ni 1.474) and rough metals, RECURSION 16: Fresnel, metallic and roulette branches
     _upload(gpu_ctx, obiwan, gradient_env())
