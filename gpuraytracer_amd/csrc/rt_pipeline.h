@@ -679,6 +679,104 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_first_pool(DScene sc, DBvh
     wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(pc.tris));
 }
 
+// The tail of the batch in one launch.  After a few bounces a small fraction of the paths is still under way, and
+// a stage of the pipeline over so few records takes as long as its chain of dependent memory accesses, whatever
+// the record count: 45-60 us per kernel plus launch gaps and the early-stop read-back, three kernels per depth
+// (12 depths of that are a fifth of a RECURSION 16 batch).  Here every lane walks the rest of its path: closest
+// hit, shading, probe in place, rest of the bounce, next bounce, as in the single-kernel form but starting from
+// the records of the extend queue and with the hierarchy.  Lanes of a wave end at different depths, which does
+// not matter for so few paths; the kept light results stay in registers.
+#ifndef RT_TAIL_FIRST_CHECK
+#define RT_TAIL_FIRST_CHECK 2     // the host first looks at the queue size after this depth
+#endif
+__global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth0,
+                                                           int q_in, const uint32_t *__restrict__ coins,
+                                                           uint32_t paths_per_sample, int max_depth) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    __shared__ int stack_mem[BVH_STACK * 64 * WG_WAVES];
+    __shared__ v4f top_mem[BVH_TOP_NODES * 4];
+    __shared__ v4f light_top_mem[BVH_LIGHT_TOP_NODES * 4];
+    BvhScratch ws;
+    ws.stack = stack_mem + (threadIdx.x >> 6) * (BVH_STACK * 64) + lane;
+    ws.top = (lds_v4f_ptr)top_mem;
+    ws.n_top = bvh_stage_top(bv, top_mem);
+    BvhScratch lws = ws;
+    lws.top = (lds_v4f_ptr)light_top_mem;
+    lws.n_top = bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES);
+    BvhCounters bc, pc;
+    bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
+    uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0;
+    const uint32_t total = b.n_ext[q_in][wave];
+    const size_t region = (size_t)wave * b.region_cap;
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const bool live = base + lane < total;
+        PathState ps;
+        uint32_t id = 0, kept_flags = 0;
+        load_path_rec(b, q_in, region + (live ? base + lane : 0u), ps, id, kept_flags);
+        ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
+        if (live && (kept_flags & KEPT_DIFF)) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
+        if (live && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
+        const uint32_t coin_row = (live ? id / paths_per_sample : 0u) * (uint32_t)max_depth;
+        bool alive = live;
+        for (int depth = depth0; depth < max_depth; depth++) {
+            if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+            n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(alive));
+            Ray ray; ray.o = ps.o; ray.d = ps.d;
+            f4 isec;
+            const int hit = closest_hit_bvh(sc, bv, ray, alive, 0, sc.count, -1, 1.0f, ws, isec, bc);
+            const float inv_det = 1.0f / isec.w;
+            const bool coin_diffuse = coins[coin_row + (uint32_t)depth] != 0u;
+            Bounce bn;
+            bn.kind = PROBE_NONE; bn.max_t = 0.0f; bn.w = 0.0f; bn.roughness = 0.0f;
+            bn.c = bn.lit = bn.albedo = bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
+            bool shaded = false;
+            if (alive) {
+                if (hit < 0) {
+                    ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
+                } else {
+                    shade_pre(sc, fr, ps, hit, isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, coin_diffuse, bn);
+                    shaded = true;
+                }
+            }
+            Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
+            const bool run_s = shaded && coin_diffuse && bn.kind == PROBE_SHADOW;
+            const bool run_g = shaded && !coin_diffuse && bn.kind == PROBE_GLOSSY;
+            bool blocked = true;
+            if (__builtin_amdgcn_ballot_w64(run_s) != 0ull) {
+                blocked = shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run_s, ws, pc);
+                n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_s));
+            }
+            int outcome = 0, light_id = -1;
+            f4 lsec;
+            lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
+            if (__builtin_amdgcn_ballot_w64(run_g) != 0ull) {
+                outcome = glossy_search_bvh(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, pc);
+                n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_g));
+            }
+            bool go_on = false;
+            if (shaded) {
+                if (coin_diffuse) go_on = finish_diffuse(sc, ps, hit, run_s && !blocked, bn.lit, bn.albedo, bn.roughness);
+                else go_on = finish_glossy(sc, fr, ps, hit, run_g ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
+            }
+            go_on = go_on && (depth + 1 < max_depth);
+            if (alive && !go_on) finish_path(b, id, ps);
+            alive = alive && go_on;
+        }
+    }
+    if (lane == 0) {
+        b.n_shadow[wave] = 0;
+        b.n_glossy[wave] = 0;
+        b.n_ext[q_in ^ 1][wave] = 0;
+    }
+    wstat_add(b, WSTAT_RAYS, n_rays);
+    wstat_add(b, WSTAT_SHADOW, n_shadow);
+    wstat_add(b, WSTAT_GLOSSY, n_glossy);
+    wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
+    wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
+    wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(pc.nodes));
+    wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(pc.tris));
+}
+
 // Shade stage of the unfused form.
 template <bool FIRST>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
@@ -1288,12 +1386,12 @@ struct Pipeline {
     // Renders the `n` samples listed in d_samples and adds them to `sum`.
     hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                    const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                   bool pool, bool in_place, rt_stats *host_stats, const char **what);
+                   bool pool, bool in_place, int tail_div, rt_stats *host_stats, const char **what);
 };
 
 inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                                 const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                                bool pool, bool in_place, rt_stats *host_stats, const char **what) {
+                                bool pool, bool in_place, int tail_div, rt_stats *host_stats, const char **what) {
     const bool use_bvh = bvh.enabled != 0;
     // lane refill needs the hierarchy; it shades depth >= 1 in a kernel of its own
     const bool use_refill = use_bvh && refill && fused;
@@ -1395,13 +1493,23 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         PIPE_TRY(hipGetLastError());
         PIPE_TRY(stamp(-1));
         q_in ^= 1;
-        // deep paths are rare: from depth 4 on, stop as soon as the next extend queue is empty
-        if (depth >= 3 && depth + 1 < max_depth) {
+        // Deep paths are rare.  From depth 3 on the host looks at the size of the next extend queue: it stops when
+        // the queue is empty, and hands what is left to the tail kernel once that is a small fraction of the batch.
+        const bool use_tail = use_bvh && fused && tail_div > 0;
+        if (depth >= (use_tail ? RT_TAIL_FIRST_CHECK : 3) && depth + 1 < max_depth) {
             hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(256), 0, stream, buf.n_ext[q_in], PIPE_WAVES, buf.total);
             PIPE_TRY(hipGetLastError());
             PIPE_TRY(hipMemcpyAsync(h_count, buf.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             PIPE_TRY(hipStreamSynchronize(stream));
             if (h_count[0] == 0) break;
+            if (use_tail && (size_t)h_count[0] * (size_t)tail_div <= paths) {
+                PIPE_TRY(stamp(0));
+                hipLaunchKernelGGL(k_tail, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth + 1, q_in, d_coins, pps,
+                                   max_depth);
+                PIPE_TRY(hipGetLastError());
+                PIPE_TRY(stamp(-1));
+                break;
+            }
         }
     }
     hipLaunchKernelGGL(k_resolve, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,

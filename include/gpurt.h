@@ -182,6 +182,10 @@ int rt_reset_stats(rt_context *ctx);
  *   "refill"        1 = traversal kernels hand finished lanes new rays (needs the hierarchy and fuse_shade = 1),
  *                   0 = every wave processes its queue in chunks of 64, -1 = by scene size (default: from 65536
  *                   triangles on); results are identical
+ *   "tail"          n > 0: once at most 1/n of a pass's paths is still under way (looked at after the third
+ *                   bounce and every later one), one kernel walks the rest of every such path instead of three
+ *                   launches per further bounce (default 64; needs the hierarchy and fuse_shade = 1); 0 = never;
+ *                   results are identical
  *   "first_in_place" 1 = depth 0 runs in one kernel and its light probes run in place (default, faster),
  *                   0 = depth 0 goes through the queues like the deeper bounces; results are identical
  *   "pool"          1 = at depth 0 the waves of a workgroup pool their light probes and draw dense packets from
