@@ -689,6 +689,8 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_first_pool(DScene sc, DBvh
 #ifndef RT_TAIL_FIRST_CHECK
 #define RT_TAIL_FIRST_CHECK 2     // the host first looks at the queue size after this depth
 #endif
+// ONE: a single bounce of every path with its probe in place; the survivors go to the next extend queue.
+template <bool ONE>
 __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth0,
                                                            int q_in, const uint32_t *__restrict__ coins,
                                                            uint32_t paths_per_sample, int max_depth) {
@@ -705,7 +707,8 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
     lws.n_top = bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES);
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
-    uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0;
+    uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
+    const int depth_end = ONE ? (depth0 + 1 < max_depth ? depth0 + 1 : max_depth) : max_depth;
     const uint32_t total = b.n_ext[q_in][wave];
     const size_t region = (size_t)wave * b.region_cap;
     for (uint32_t base = 0; base < total; base += 64u) {
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
         if (live && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
         const uint32_t coin_row = (live ? id / paths_per_sample : 0u) * (uint32_t)max_depth;
         bool alive = live;
-        for (int depth = depth0; depth < max_depth; depth++) {
+        for (int depth = depth0; depth < depth_end; depth++) {
             if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
             n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(alive));
             Ray ray; ray.o = ps.o; ray.d = ps.d;
@@ -755,18 +758,31 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
             }
             bool go_on = false;
             if (shaded) {
-                if (coin_diffuse) go_on = finish_diffuse(sc, ps, hit, run_s && !blocked, bn.lit, bn.albedo, bn.roughness);
-                else go_on = finish_glossy(sc, fr, ps, hit, run_g ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
+                if (coin_diffuse) {
+                    const bool written = run_s && !blocked;
+                    go_on = finish_diffuse(sc, ps, hit, written, bn.lit, bn.albedo, bn.roughness);
+                    if (ONE && written) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
+                } else {
+                    go_on = finish_glossy(sc, fr, ps, hit, run_g ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
+                    if (ONE && run_g && outcome != 0) {
+                        b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
+                        kept_flags |= KEPT_SPEC;
+                    }
+                }
             }
             go_on = go_on && (depth + 1 < max_depth);
             if (alive && !go_on) finish_path(b, id, ps);
             alive = alive && go_on;
         }
+        if (ONE) {      // whole waves: the queue position comes from a ballot
+            const uint32_t slot = region_slot(fill_next, alive);
+            if (alive) store_path_rec(b, q_in ^ 1, region + slot, ps, id, kept_flags);
+        }
     }
     if (lane == 0) {
         b.n_shadow[wave] = 0;
         b.n_glossy[wave] = 0;
-        b.n_ext[q_in ^ 1][wave] = 0;
+        b.n_ext[q_in ^ 1][wave] = fill_next;
     }
     wstat_add(b, WSTAT_RAYS, n_rays);
     wstat_add(b, WSTAT_SHADOW, n_shadow);
@@ -1386,12 +1402,12 @@ struct Pipeline {
     // Renders the `n` samples listed in d_samples and adds them to `sum`.
     hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                    const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                   bool pool, bool in_place, int tail_div, rt_stats *host_stats, const char **what);
+                   bool pool, bool in_place, int tail_div, int inplace_depths, rt_stats *host_stats, const char **what);
 };
 
 inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                                 const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                                bool pool, bool in_place, int tail_div, rt_stats *host_stats, const char **what) {
+                                bool pool, bool in_place, int tail_div, int inplace_depths, rt_stats *host_stats, const char **what) {
     const bool use_bvh = bvh.enabled != 0;
     // lane refill needs the hierarchy; it shades depth >= 1 in a kernel of its own
     const bool use_refill = use_bvh && refill && fused;
@@ -1453,6 +1469,15 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
             q_in ^= 1;
             continue;
         }
+        if (use_bvh && fused && depth > 0 && depth <= inplace_depths) {
+            // this bounce with its probes in place, as at depth 0
+            hipLaunchKernelGGL(k_tail<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, d_coins, pps,
+                               max_depth);
+            PIPE_TRY(hipGetLastError());
+            PIPE_TRY(stamp(-1));
+            q_in ^= 1;
+            continue;
+        }
         if (use_refill && depth > 0) {
             hipLaunchKernelGGL(k_extend_refill, grid, block, 0, stream, sc, bvh, buf, q_in);
             PIPE_TRY(hipGetLastError());
@@ -1504,7 +1529,7 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
             if (h_count[0] == 0) break;
             if (use_tail && (size_t)h_count[0] * (size_t)tail_div <= paths) {
                 PIPE_TRY(stamp(0));
-                hipLaunchKernelGGL(k_tail, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth + 1, q_in, d_coins, pps,
+                hipLaunchKernelGGL(k_tail<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth + 1, q_in, d_coins, pps,
                                    max_depth);
                 PIPE_TRY(hipGetLastError());
                 PIPE_TRY(stamp(-1));

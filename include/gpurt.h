@@ -186,6 +186,8 @@ int rt_reset_stats(rt_context *ctx);
  *                   bounce and every later one), one kernel walks the rest of every such path instead of three
  *                   launches per further bounce (default 64; needs the hierarchy and fuse_shade = 1); 0 = never;
  *                   results are identical
+ *   "inplace_depths" n: the n bounces after the first also run their light probes in place instead of through
+ *                   the probe queues (default 0: 1 % slower when on); results are identical
  *   "first_in_place" 1 = depth 0 runs in one kernel and its light probes run in place (default, faster),
  *                   0 = depth 0 goes through the queues like the deeper bounces; results are identical
  *   "pool"          1 = at depth 0 the waves of a workgroup pool their light probes and draw dense packets from
