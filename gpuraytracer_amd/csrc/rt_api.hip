@@ -54,6 +54,10 @@ struct rt_context {
     // per-launch sample tables
     uint32_t *d_samples = nullptr, *d_light_seeds = nullptr;
     uint32_t sample_cap = 0;
+    // pinned staging for the two tables, two slots used in turn (see Pipeline::h_coins)
+    uint32_t *h_tables[2] = {nullptr, nullptr};
+    hipEvent_t tables_copied[2] = {nullptr, nullptr};
+    int table_slot = 0;
     uint32_t chain_pos = 0, chain_val = 0;   // light-seed chain: chain_val = hash^chain_pos(clock)
     bool chain_valid = false;
 
@@ -248,6 +252,12 @@ int ensure_sample_tables(rt_context *ctx, uint32_t n) {
     ctx->sample_cap = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_samples, sizeof(uint32_t) * n));
     HIP_TRY(ctx, hipMalloc(&ctx->d_light_seeds, sizeof(uint32_t) * n));
+    for (int k = 0; k < 2; k++) {
+        if (ctx->h_tables[k]) (void)hipHostFree(ctx->h_tables[k]);      // hipFree above has drained the device
+        ctx->h_tables[k] = nullptr;
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_tables[k], sizeof(uint32_t) * 2 * n));
+        if (!ctx->tables_copied[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->tables_copied[k], hipEventDisableTiming));
+    }
     ctx->sample_cap = n;
     return RT_OK;
 }
@@ -288,6 +298,10 @@ int rt_destroy(rt_context *ctx) {
     if (ctx->d_sum_own) (void)hipFree(ctx->d_sum_own);
     if (ctx->d_samples) (void)hipFree(ctx->d_samples);
     if (ctx->d_light_seeds) (void)hipFree(ctx->d_light_seeds);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->h_tables[k]) (void)hipHostFree(ctx->h_tables[k]);
+        if (ctx->tables_copied[k]) (void)hipEventDestroy(ctx->tables_copied[k]);
+    }
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -546,18 +560,22 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
     }
     int rc = ensure_sample_tables(ctx, chunk_max);
     if (rc) return rc;
-    std::vector<uint32_t> samples(chunk_max), seeds(chunk_max);
 
     for (uint32_t done = 0; done < sample_count;) {
         const uint32_t n = (sample_count - done < chunk_max) ? sample_count - done : chunk_max;
+        // The uploads are queued behind the previous pass's kernels on the stream, so the device copies cannot be
+        // overwritten early; the pinned slot must not be refilled before its own copy has run.
+        const int slot = ctx->table_slot;
+        ctx->table_slot ^= 1;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->tables_copied[slot]));
+        uint32_t *samples = ctx->h_tables[slot], *seeds = samples + ctx->sample_cap;
         for (uint32_t k = 0; k < n; k++) {
             samples[k] = sample_begin + (done + k) * sample_stride;
             seeds[k] = light_seed_for(ctx, samples[k]);
         }
-        // the tables of the previous chunk may still be in use by queued kernels
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_samples, samples.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_light_seeds, seeds.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_samples, samples, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_light_seeds, seeds, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->tables_copied[slot], ctx->stream));
         if (ctx->profiling && ctx->pipeline == 0) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (ctx->pipeline == 0) {
             const uint32_t tiles = ((ctx->width + 7u) >> 3) * ((ctx->height + 7u) >> 3);
@@ -566,7 +584,7 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
             HIP_TRY(ctx, hipGetLastError());
         } else {
             const char *msg = nullptr;
-            ctx->pipe.h_light_seeds.assign(seeds.begin(), seeds.begin() + n);
+            ctx->pipe.h_light_seeds.assign(seeds, seeds + n);
             const bool acc = use_accel(ctx);
             hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame,
                                          ctx->d_sum, ctx->d_samples, (int)n, ctx->stream, ctx->profiling != 0,

@@ -1263,6 +1263,11 @@ struct Pipeline {
     size_t cap_paths = 0;
     uint32_t *d_coins = nullptr;
     size_t cap_coins = 0;
+    // pinned staging for the coin table, two slots used in turn: the upload of a pass is queued behind the previous
+    // pass's kernels, so the host must not overwrite a slot before its copy has run (the slot's event tells)
+    uint32_t *h_coins[2] = {nullptr, nullptr};
+    hipEvent_t coins_copied[2] = {nullptr, nullptr};
+    int coin_slot = 0;
     uint32_t *h_count = nullptr;   // pinned, for the early-stop read-back
     // Profiling: events are recorded around every stage launch and turned into times lazily
     // (collect_times), so that the timed region carries no extra synchronisation.
@@ -1289,6 +1294,12 @@ struct Pipeline {
         (void)hipFree(buf.n_ext[0]); (void)hipFree(buf.n_ext[1]); (void)hipFree(buf.n_shadow); (void)hipFree(buf.n_glossy);
         (void)hipFree(buf.wstats); (void)hipFree(buf.total);
         (void)hipFree(d_coins);
+        for (int k = 0; k < 2; k++) {
+            if (h_coins[k]) (void)hipHostFree(h_coins[k]);
+            if (coins_copied[k]) (void)hipEventDestroy(coins_copied[k]);
+            h_coins[k] = nullptr;
+            coins_copied[k] = nullptr;
+        }
         if (h_count) (void)hipHostFree(h_count);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         events.clear();
@@ -1346,6 +1357,18 @@ struct Pipeline {
             d_coins = nullptr;
             cap_coins = 0;
             PIPE_ALLOC(d_coins, sizeof(uint32_t) * coins);
+            for (int k = 0; k < 2; k++) {
+                if (h_coins[k]) (void)hipHostFree(h_coins[k]);      // hipFree above has drained the device
+                h_coins[k] = nullptr;
+                *what = "h_coins";
+                e = hipHostMalloc((void **)&h_coins[k], sizeof(uint32_t) * coins);
+                if (e != hipSuccess) return e;
+                if (!coins_copied[k]) {
+                    *what = "coins_copied";
+                    e = hipEventCreateWithFlags(&coins_copied[k], hipEventDisableTiming);
+                    if (e != hipSuccess) return e;
+                }
+            }
             cap_coins = coins;
         }
         if (!h_count) {
@@ -1421,7 +1444,11 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
     buf.region_cap = region_cap_for(paths);
 
     // coin[slot][depth] = unitFloat(light_seed) < 0.5 after `depth` earlier draws (raytracer.glsl:553)
-    std::vector<uint32_t> coins((size_t)n * max_depth);
+#define PIPE_TRY(expr) do { *what = #expr; e = (expr); if (e != hipSuccess) return e; } while (0)
+    const int cs = coin_slot;
+    coin_slot ^= 1;
+    PIPE_TRY(hipEventSynchronize(coins_copied[cs]));
+    uint32_t *coins = h_coins[cs];
     for (int k = 0; k < n; k++) {
         uint32_t ls = h_light_seeds[k];
         for (int d = 0; d < max_depth; d++) {
@@ -1431,9 +1458,8 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
             coins[(size_t)k * max_depth + d] = ((float)ls * (1.0f / 4294967296.0f) < 0.5f) ? 1u : 0u;
         }
     }
-#define PIPE_TRY(expr) do { *what = #expr; e = (expr); if (e != hipSuccess) return e; } while (0)
-    PIPE_TRY(hipMemcpyAsync(d_coins, coins.data(), sizeof(uint32_t) * coins.size(), hipMemcpyHostToDevice, stream));
-    PIPE_TRY(hipStreamSynchronize(stream));   // `coins` is a local
+    PIPE_TRY(hipMemcpyAsync(d_coins, coins, sizeof(uint32_t) * (size_t)n * max_depth, hipMemcpyHostToDevice, stream));
+    PIPE_TRY(hipEventRecord(coins_copied[cs], stream));
 
     if (profiling && ev_used > 8192) PIPE_TRY(collect_times(host_stats));
     auto stamp = [&](int kind_of_next_interval) -> hipError_t {
