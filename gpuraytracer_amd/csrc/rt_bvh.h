@@ -129,20 +129,20 @@ struct TravState {
 // Advances every running lane of the wave.  `leaf(slot)` is called for every triangle slot of every leaf whose
 // box the ray enters within t_limit(); it returns false to stop that lane's traversal (any-hit found).
 // Returns when no lane runs any more, or as soon as at least `stop_at` lanes of the wave are not running
-// (pass 65 to run to the end).
+// (pass 65 to run to the end; `at_least_one`: not before one round of node steps and leaves has been done).
 // "while-while" order: all lanes first descend through inner nodes until each holds a leaf (or has finished),
 // then all leaves are processed together; this keeps box tests and triangle tests of a wave from
 // interleaving lane by lane.
 template <typename LeafFn, typename LimitFn>
 RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const BvhScratch &ws, TravState &ts, int stop_at, LeafFn leaf,
-                        LimitFn t_limit, BvhCounters &cnt) {
+                        LimitFn t_limit, BvhCounters &cnt, bool at_least_one = false) {
     int *stack = ws.stack;
     int sp = ts.sp;
     int node = ts.node;
     bool run = ts.run;
-    for (;;) {
+    for (;; at_least_one = false) {
         const unsigned long long running = __builtin_amdgcn_ballot_w64(run);
-        if (running == 0ull || 64 - (int)__popcll(running) >= stop_at) break;
+        if (running == 0ull || (!at_least_one && 64 - (int)__popcll(running) >= stop_at)) break;
         // a divergent loop: lanes leave as they reach a leaf or finish, and the wave goes on when none is left
         while (run && node >= 0) {
             v4f q0, q1, q2, q3;
@@ -288,6 +288,75 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
     return cf.best;
 }
 
+// Any-hit search in which the lanes of a wave share the work.  An any-hit query is an OR over the subtrees on a
+// ray's stack, so a lane with nothing to do (no query of its own, or done early: these searches end at very
+// different times) can take the top stack entry of a lane that is still busy, together with that lane's ray, and
+// search that subtree for it.  A hit is reported through a flag of the query's owner in LDS; every helper of
+// the same owner sees it and stops.  `scratch` points to 128 bytes of LDS of this wave.
+// test(ray, extra, slot) is the triangle test (it includes the exclusion of the triangle the ray starts on).
+#ifndef RT_SHARE_MIN_IDLE
+#define RT_SHARE_MIN_IDLE 16
+#endif
+constexpr int SHARE_MIN_IDLE = RT_SHARE_MIN_IDLE;
+typedef volatile __attribute__((address_space(3))) unsigned char *lds_u8_ptr;
+
+RT_DEV float lane_read(float v, int lane4) { return __int_as_float(__builtin_amdgcn_ds_bpermute(lane4, __float_as_int(v))); }
+
+template <typename TestFn>
+RT_DEV bool anyhit_shared(const DBvh &bv, const BvhScratch &ws, lds_u8_ptr scratch, Ray ray, float lim, f3 extra, bool active,
+                          TestFn test, BvhCounters &cnt) {
+    const int lane = (int)(threadIdx.x & 63u);
+    lds_u8_ptr flags = scratch, table = scratch + 64;
+    flags[lane] = 0;
+    int owner = lane;
+    BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    TravState ts;
+    ts.node = 0; ts.sp = 0; ts.run = active;
+    auto leaf = [&](int slot) -> bool {
+        if (test(ray, extra, slot)) { flags[owner] = 1; return false; }
+        return true;
+    };
+    auto limit = [&]() -> float { return lim; };
+    for (;;) {
+        if (ts.run && flags[owner] != 0) ts.run = false;          // another helper of this query has found a hit
+        const unsigned long long running = __builtin_amdgcn_ballot_w64(ts.run);
+        if (running == 0ull) break;
+        const unsigned long long donors = __builtin_amdgcn_ballot_w64(ts.run && ts.sp > 0);
+        const int n_idle = 64 - (int)__popcll(running), n_donors = (int)__popcll(donors);
+        if (n_idle >= SHARE_MIN_IDLE && n_donors > 0) {
+            const int n_take = n_idle < n_donors ? n_idle : n_donors;
+            const unsigned long long idle = ~running;
+            const int d_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
+            const int i_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const bool gives = ts.run && ts.sp > 0 && d_rank < n_take;
+            const bool takes = !ts.run && i_rank < n_take;
+            if (gives) table[d_rank] = (unsigned char)lane;
+            // the entry a donor hands over: the top of its stack
+            int given = 0;
+            if (gives) { ts.sp--; given = ws.stack[64 * ts.sp]; }
+            const int from4 = takes ? 4 * (int)table[i_rank] : 4 * lane;
+            // every lane publishes its state; a taker reads its donor's
+            const int t_node = __builtin_amdgcn_ds_bpermute(from4, given);
+            const int t_owner = __builtin_amdgcn_ds_bpermute(from4, owner);
+            Ray r2; BvhRay b2; f3 e2;
+            r2.o = mk3(lane_read(ray.o.x, from4), lane_read(ray.o.y, from4), lane_read(ray.o.z, from4));
+            r2.d = mk3(lane_read(ray.d.x, from4), lane_read(ray.d.y, from4), lane_read(ray.d.z, from4));
+            b2.inv = mk3(lane_read(br.inv.x, from4), lane_read(br.inv.y, from4), lane_read(br.inv.z, from4));
+            b2.oi_lo = mk3(lane_read(br.oi_lo.x, from4), lane_read(br.oi_lo.y, from4), lane_read(br.oi_lo.z, from4));
+            b2.oi_hi = mk3(lane_read(br.oi_hi.x, from4), lane_read(br.oi_hi.y, from4), lane_read(br.oi_hi.z, from4));
+            e2 = mk3(lane_read(extra.x, from4), lane_read(extra.y, from4), lane_read(extra.z, from4));
+            const float l2 = lane_read(lim, from4);
+            if (takes) {
+                ray = r2; br.inv = b2.inv; br.oi_lo = b2.oi_lo; br.oi_hi = b2.oi_hi; extra = e2; lim = l2;
+                owner = t_owner;
+                ts.node = t_node; ts.sp = 0; ts.run = true;
+            }
+        }
+        bvh_advance(bv, br, ws, ts, SHARE_MIN_IDLE, leaf, limit, cnt, true);
+    }
+    return flags[lane] != 0;
+}
+
 // sampleLight's occlusion query (raytracer.glsl:372-378): is any triangle != current hit by
 // intersectTriangleShadow within max_t?
 RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
@@ -354,6 +423,63 @@ RT_DEV int glossy_search_bvh(const DScene &sc, const DBvh &bv, const DBvh &lbv, 
         light_id = closest_hit_range(sc.geo, 0, lights, ray, active, current, isec, -1);
     }
     const bool blocked = (lights < count) && closer_any_hit_bvh(sc, bv, ray, isec, current, active, ws, cnt);
+    if (blocked) return 0;
+    return light_id < 0 ? 1 : 2;
+}
+
+// shadow_any_hit_bvh and glossy_search_bvh with the any-hit part shared among the lanes of the wave (anyhit_shared).
+RT_DEV bool shadow_any_hit_shared(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
+                                  const BvhScratch &ws, lds_u8_ptr scratch, BvhCounters &cnt) {
+    const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
+    const bool ok = ((s - s) == 0.0f) && ((max_t - max_t) == 0.0f);
+    auto test = [&](const Ray &r, const f3 &e, int slot) -> bool {
+        const Tri t = load_leaf_tri(bv, slot);
+        return intersect_triangle_shadow(r, t, e.x) && leaf_tri_id(bv, slot) != __float_as_int(e.z);
+    };
+    bool blocked = anyhit_shared(bv, ws, scratch, ray, max_t * BVH_NEAR, mk3(max_t, 0.0f, __int_as_float(current)), active && ok,
+                                 test, cnt);
+    const bool redo = active && !ok;
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+        const bool b2 = shadow_any_hit_bf(sc, ray, max_t, current, redo);
+        if (redo) blocked = b2;
+    }
+    return blocked;
+}
+
+RT_DEV int glossy_search_shared(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &ray, int current, bool active,
+                                int &light_id, f4 &isec, const BvhScratch &ws, const BvhScratch &lws, lds_u8_ptr scratch,
+                                BvhCounters &cnt) {
+    const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
+    if (lbv.enabled) {
+        light_id = closest_hit_bvh(sc, lbv, ray, active, 0, lights, current, 0.0f, lws, isec, cnt);
+    } else {
+        isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
+        light_id = closest_hit_range(sc.geo, 0, lights, ray, active, current, isec, -1);
+    }
+    bool blocked = false;
+    if (lights < count) {
+        const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
+        const bool bounded = isec.z >= 0.0f;                 // a light was hit: only triangles not farther than it matter
+        const float t_light = isec.z / isec.w;
+        const bool ok = ((s - s) == 0.0f) && (!bounded || (t_light - t_light) == 0.0f);
+        auto test = [&](const Ray &r, const f3 &e, int slot) -> bool {
+            const Tri t = load_leaf_tri(bv, slot);
+            f4 st;
+            st.x = 0.0f; st.y = 0.0f; st.z = e.x; st.w = e.y;
+            PlaneTest pt;
+            float rx, ry;
+            if (!(plane_test_closest(r, t, st, pt) && inside_test(r, t, pt, rx, ry))) return false;
+            const int id = leaf_tri_id(bv, slot);
+            return id >= lights && id != __float_as_int(e.z);
+        };
+        blocked = anyhit_shared(bv, ws, scratch, ray, bounded ? t_light * BVH_NEAR : __builtin_inff(),
+                                mk3(isec.z, isec.w, __int_as_float(current)), active && ok, test, cnt);
+        const bool redo = active && !ok;
+        if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+            const bool b2 = closer_any_hit_range(sc.geo, lights, count, ray, isec, current, redo);
+            if (redo) blocked = b2;
+        }
+    }
     if (blocked) return 0;
     return light_id < 0 ? 1 : 2;
 }

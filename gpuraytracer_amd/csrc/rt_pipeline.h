@@ -283,8 +283,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
 // coin (raytracer.glsl:553: light_seed depends on SAMPLE and depth only) and run the same kind of probe, from
 // neighbouring surface points: the probe can run in place with full lanes, and the probe records (112 bytes
 // per path written and read back) are never made.  Deeper bounces mix samples in a wave and keep the queues.
-template <bool BVH>
-__global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
+template <bool BVH, bool SHARE = false>
+__global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
                                                          const uint32_t *__restrict__ samples,
                                                          const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
                                                          uint32_t n_slots, int max_depth) {
@@ -300,7 +300,9 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
     ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
     BvhScratch lws = ws;
     lws.top = (lds_v4f_ptr)light_top_mem;
-    lws.n_top = BVH ? bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES) : 0;
+    // SHARE: the last 1 KB of the light hierarchy's cache holds 128 bytes per wave for anyhit_shared
+    lws.n_top = BVH ? bvh_stage_top(lbv, light_top_mem, SHARE ? BVH_LIGHT_TOP_NODES - 16 : BVH_LIGHT_TOP_NODES) : 0;
+    lds_u8_ptr share = (lds_u8_ptr)&light_top_mem[(BVH_LIGHT_TOP_NODES - 16) * 4] + 128 * (threadIdx.x >> 6);
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
     uint32_t n_paths = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
@@ -350,7 +352,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
             const bool run = shaded && bn.kind == PROBE_SHADOW;
             bool blocked = true;
             if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                blocked = BVH ? shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run, ws, pc)
+                blocked = SHARE ? shadow_any_hit_shared(sc, bv, probe, bn.max_t, hit, run, ws, share, pc)
+                          : BVH ? shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run, ws, pc)
                               : shadow_any_hit_bf(sc, probe, bn.max_t, hit, run);
                 n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             }
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_first(DScene sc, DBvh bv, DBv
             f4 lsec;
             lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
             if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                outcome = BVH ? glossy_search_bvh(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, pc)
+                outcome = SHARE ? glossy_search_shared(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, share, pc)
+                          : BVH ? glossy_search_bvh(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, pc)
                               : glossy_search_bf(sc, probe, hit, run, light_id, lsec);
                 n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             }
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_first_pool(DScene sc, DBvh
 #define RT_TAIL_FIRST_CHECK 2     // the host first looks at the queue size after this depth
 #endif
 // ONE: a single bounce of every path with its probe in place; the survivors go to the next extend queue.
-template <bool ONE>
+template <bool ONE, bool SHARE>
 __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth0,
                                                            int q_in, const uint32_t *__restrict__ coins,
                                                            uint32_t paths_per_sample, int max_depth) {
@@ -704,7 +708,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
     ws.n_top = bvh_stage_top(bv, top_mem);
     BvhScratch lws = ws;
     lws.top = (lds_v4f_ptr)light_top_mem;
-    lws.n_top = bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES);
+    // SHARE: the last 1 KB of the light hierarchy's cache holds 128 bytes per wave for anyhit_shared
+    lws.n_top = bvh_stage_top(lbv, light_top_mem, SHARE ? BVH_LIGHT_TOP_NODES - 16 : BVH_LIGHT_TOP_NODES);
+    lds_u8_ptr share = (lds_u8_ptr)&light_top_mem[(BVH_LIGHT_TOP_NODES - 16) * 4] + 128 * (threadIdx.x >> 6);
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
     uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
@@ -746,14 +752,16 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
             const bool run_g = shaded && !coin_diffuse && bn.kind == PROBE_GLOSSY;
             bool blocked = true;
             if (__builtin_amdgcn_ballot_w64(run_s) != 0ull) {
-                blocked = shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run_s, ws, pc);
+                blocked = SHARE ? shadow_any_hit_shared(sc, bv, probe, bn.max_t, hit, run_s, ws, share, pc)
+                                : shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run_s, ws, pc);
                 n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_s));
             }
             int outcome = 0, light_id = -1;
             f4 lsec;
             lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
             if (__builtin_amdgcn_ballot_w64(run_g) != 0ull) {
-                outcome = glossy_search_bvh(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, pc);
+                outcome = SHARE ? glossy_search_shared(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, share, pc)
+                                : glossy_search_bvh(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, pc);
                 n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_g));
             }
             bool go_on = false;
@@ -881,7 +889,7 @@ RT_DEV bool retire_glossy(const DScene &sc, const DFrame &fr, const PipeBuffers 
 }
 
 // Shadow-probe stage: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579.
-template <bool BVH>
+template <bool BVH, bool SHARE = false>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in,
                                                                 int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
@@ -891,6 +899,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh 
     ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
     ws.top = (lds_v4f_ptr)top_mem;
     ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
+    __shared__ unsigned char share_mem[SHARE ? 128 * WG_WAVES : 1];
+    lds_u8_ptr share = (lds_u8_ptr)share_mem + (SHARE ? 128 * (threadIdx.x >> 6) : 0);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const size_t region = (size_t)wave * b.region_cap;
@@ -902,7 +912,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh 
         const size_t i = region + (live ? base + lane : 0u);
         ProbeHead h;
         load_probe_head(b, i, h);
-        const bool blocked = BVH ? shadow_any_hit_bvh(sc, bv, h.probe, h.max_t, h.current, live, ws, bc)
+        const bool blocked = SHARE ? shadow_any_hit_shared(sc, bv, h.probe, h.max_t, h.current, live, ws, share, bc)
+                             : BVH ? shadow_any_hit_bvh(sc, bv, h.probe, h.max_t, h.current, live, ws, bc)
                                  : shadow_any_hit_bf(sc, h.probe, h.max_t, h.current, live);
         PathState ps;
         uint32_t kept_flags = 0;
@@ -919,7 +930,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh 
 }
 
 // Glossy-probe stage: search of sampleLightGlossy (raytracer.glsl:403-437), then :557-579.
-template <bool BVH>
+template <bool BVH, bool SHARE = false>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
                                                                 int depth, int q_in, int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
@@ -932,7 +943,9 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
     __shared__ v4f light_top_mem[BVH ? BVH_LIGHT_TOP_NODES * 4 : 1];
     BvhScratch lws = ws;
     lws.top = (lds_v4f_ptr)light_top_mem;
-    lws.n_top = BVH ? bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES) : 0;
+    // SHARE: the last 1 KB of the light hierarchy's cache holds 128 bytes per wave for anyhit_shared
+    lws.n_top = BVH ? bvh_stage_top(lbv, light_top_mem, SHARE ? BVH_LIGHT_TOP_NODES - 16 : BVH_LIGHT_TOP_NODES) : 0;
+    lds_u8_ptr share = (lds_u8_ptr)&light_top_mem[BVH ? (BVH_LIGHT_TOP_NODES - 16) * 4 : 0] + (SHARE ? 128 * (threadIdx.x >> 6) : 0);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const size_t region = (size_t)wave * b.region_cap;
@@ -947,7 +960,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
         load_probe_head(b, i, h);
         int light_id;
         f4 lsec;
-        const int outcome = BVH ? glossy_search_bvh(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, bc)
+        const int outcome = SHARE ? glossy_search_shared(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, share, bc)
+                            : BVH ? glossy_search_bvh(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, bc)
                                 : glossy_search_bf(sc, h.probe, h.current, live, light_id, lsec);
         PathState ps;
         uint32_t kept_flags = 0;
@@ -1425,12 +1439,12 @@ struct Pipeline {
     // Renders the `n` samples listed in d_samples and adds them to `sum`.
     hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                    const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                   bool pool, bool in_place, int tail_div, int inplace_depths, rt_stats *host_stats, const char **what);
+                   bool pool, bool in_place, int tail_div, int inplace_depths, bool share, rt_stats *host_stats, const char **what);
 };
 
 inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                                 const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                                bool pool, bool in_place, int tail_div, int inplace_depths, rt_stats *host_stats, const char **what) {
+                                bool pool, bool in_place, int tail_div, int inplace_depths, bool share, rt_stats *host_stats, const char **what) {
     const bool use_bvh = bvh.enabled != 0;
     // lane refill needs the hierarchy; it shades depth >= 1 in a kernel of its own
     const bool use_refill = use_bvh && refill && fused;
@@ -1486,6 +1500,8 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
             if (use_bvh && pool && buf.region_cap >= POOL_MIN_REGION)
                 hipLaunchKernelGGL(k_first_pool, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins, pps,
                                    (uint32_t)n, max_depth);
+            else if (use_bvh && share) hipLaunchKernelGGL((k_first<true, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf,
+                                                          d_samples, d_coins, pps, (uint32_t)n, max_depth);
             else if (use_bvh) hipLaunchKernelGGL(k_first<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins,
                                                  pps, (uint32_t)n, max_depth);
             else hipLaunchKernelGGL(k_first<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins,
@@ -1497,8 +1513,10 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         }
         if (use_bvh && fused && depth > 0 && depth <= inplace_depths) {
             // this bounce with its probes in place, as at depth 0
-            hipLaunchKernelGGL(k_tail<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, d_coins, pps,
-                               max_depth);
+            if (share) hipLaunchKernelGGL((k_tail<true, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
+                                          d_coins, pps, max_depth);
+            else hipLaunchKernelGGL((k_tail<true, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
+                                    d_coins, pps, max_depth);
             PIPE_TRY(hipGetLastError());
             PIPE_TRY(stamp(-1));
             q_in ^= 1;
@@ -1532,6 +1550,11 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         PIPE_TRY(stamp(1));
         if (use_refill) {
             hipLaunchKernelGGL(k_probe_refill, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
+        } else if (use_bvh && share) {
+            hipLaunchKernelGGL((k_probe_shadow<true, true>), grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
+            PIPE_TRY(hipGetLastError());
+            hipLaunchKernelGGL((k_probe_glossy<true, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
+                               max_depth);
         } else if (use_bvh) {
             hipLaunchKernelGGL(k_probe_shadow<true>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
             PIPE_TRY(hipGetLastError());
@@ -1555,8 +1578,10 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
             if (h_count[0] == 0) break;
             if (use_tail && (size_t)h_count[0] * (size_t)tail_div <= paths) {
                 PIPE_TRY(stamp(0));
-                hipLaunchKernelGGL(k_tail<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth + 1, q_in, d_coins, pps,
-                                   max_depth);
+                if (share) hipLaunchKernelGGL((k_tail<false, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth + 1,
+                                              q_in, d_coins, pps, max_depth);
+                else hipLaunchKernelGGL((k_tail<false, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth + 1,
+                                        q_in, d_coins, pps, max_depth);
                 PIPE_TRY(hipGetLastError());
                 PIPE_TRY(stamp(-1));
                 break;

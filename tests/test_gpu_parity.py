@@ -29,7 +29,8 @@ def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK,
     # traversal kernels with lane refill, 5 = staged, hierarchy, depth 0 with the workgroup's probe pool,
     # 6 = staged, hierarchy, depth 0 through the queues like the deeper bounces, 7 = staged, hierarchy, no tail kernel
     # (1 hands the last paths of a pass to the tail kernel as soon as at most 1/64 of them is left), 8 = the tail
-    # kernel takes whatever is left after the third bounce, 9 = the second and third bounce also run their probes in place
+    # kernel takes whatever is left after the third bounce, 9 = the second and third bounce also run their probes in place,
+    # 10 = every lane runs its own any-hit search (1: the lanes of a wave share them)
     ctx.set_option("fuse_shade", 0 if pipeline == 2 else 1)
     ctx.set_option("accel", 0 if pipeline == 3 else 1)
     ctx.set_option("refill", 1 if pipeline == 4 else 0)
@@ -37,6 +38,7 @@ def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK,
     ctx.set_option("first_in_place", 0 if pipeline == 6 else 1)
     ctx.set_option("tail", 0 if pipeline == 7 else (1 if pipeline == 8 else 64))
     ctx.set_option("inplace_depths", 2 if pipeline == 9 else 0)
+    ctx.set_option("share", 0 if pipeline == 10 else 1)
     pipeline = min(pipeline, 1)
     ctx.set_option("pipeline", pipeline)
     ctx.set_option("batch_samples", batch)
@@ -120,7 +122,7 @@ def test_hierarchy_equals_index_order_loop(gpu_ctx, name):
 REF_IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close"]
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("case", REF_IMAGE_CASES)
 def test_images_equal_reference_shader(gpu_ctx, case, pipeline):
     """Images the reference's main() wrote for single SAMPLE values, bit for bit.  The reference stores
@@ -169,7 +171,7 @@ def test_mean_equals_reference_running_mean(gpu_ctx):
     assert np.allclose(total / 16.0, want, rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
     _upload(gpu_ctx, cubes, constant_env())
     for spp in (1, 4, 16):
@@ -179,7 +181,7 @@ def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
         assert [st["pixel_samples"], st["rays"], st["shadow_probes"], st["glossy_probes"]] == g["stats"].tolist()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_image_vs_checker_gradient_env_ragged(gpu_ctx, oracle_mod, cubes, pipeline):
     # 52 x 37 is not a multiple of the 8 x 8 tile; the gradient environment exercises the bilinear lookup
     _upload(gpu_ctx, cubes, gradient_env())
