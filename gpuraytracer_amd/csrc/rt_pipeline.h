@@ -1548,7 +1548,7 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         }
 #undef LAUNCH_EXTEND
         PIPE_TRY(stamp(1));
-        if (use_refill) {
+        if (use_refill && !share) {      // shared any-hit searches beat refilled ones (1 M triangles: 8.3 vs 11.1 ms)
             hipLaunchKernelGGL(k_probe_refill, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
         } else if (use_bvh && share) {
             hipLaunchKernelGGL((k_probe_shadow<true, true>), grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
