@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
 // coin (raytracer.glsl:553: light_seed depends on SAMPLE and depth only) and run the same kind of probe, from
 // neighbouring surface points: the probe can run in place with full lanes, and the probe records (112 bytes
 // per path written and read back) are never made.  Deeper bounces mix samples in a wave and keep the queues.
-template <bool BVH, bool SHARE = false>
+template <bool BVH, int SHARE = 0>
 __global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
                                                          const uint32_t *__restrict__ samples,
                                                          const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene s
             const bool run = shaded && bn.kind == PROBE_SHADOW;
             bool blocked = true;
             if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                blocked = SHARE ? shadow_any_hit_shared(sc, bv, probe, bn.max_t, hit, run, ws, share, pc)
+                blocked = SHARE ? shadow_any_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, probe, bn.max_t, hit, run, ws, share, pc)
                           : BVH ? shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run, ws, pc)
                               : shadow_any_hit_bf(sc, probe, bn.max_t, hit, run);
                 n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene s
             f4 lsec;
             lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
             if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                outcome = SHARE ? glossy_search_shared(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, share, pc)
+                outcome = SHARE ? glossy_search_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, share, pc)
                           : BVH ? glossy_search_bvh(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, pc)
                               : glossy_search_bf(sc, probe, hit, run, light_id, lsec);
                 n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_first_pool(DScene sc, DBvh
 #define RT_TAIL_FIRST_CHECK 2     // the host first looks at the queue size after this depth
 #endif
 // ONE: a single bounce of every path with its probe in place; the survivors go to the next extend queue.
-template <bool ONE, bool SHARE>
+template <bool ONE, int SHARE>
 __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth0,
                                                            int q_in, const uint32_t *__restrict__ coins,
                                                            uint32_t paths_per_sample, int max_depth) {
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
             const bool run_g = shaded && !coin_diffuse && bn.kind == PROBE_GLOSSY;
             bool blocked = true;
             if (__builtin_amdgcn_ballot_w64(run_s) != 0ull) {
-                blocked = SHARE ? shadow_any_hit_shared(sc, bv, probe, bn.max_t, hit, run_s, ws, share, pc)
+                blocked = SHARE ? shadow_any_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, probe, bn.max_t, hit, run_s, ws, share, pc)
                                 : shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run_s, ws, pc);
                 n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_s));
             }
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
             f4 lsec;
             lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
             if (__builtin_amdgcn_ballot_w64(run_g) != 0ull) {
-                outcome = SHARE ? glossy_search_shared(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, share, pc)
+                outcome = SHARE ? glossy_search_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, share, pc)
                                 : glossy_search_bvh(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, pc);
                 n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_g));
             }
@@ -889,7 +889,7 @@ RT_DEV bool retire_glossy(const DScene &sc, const DFrame &fr, const PipeBuffers 
 }
 
 // Shadow-probe stage: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579.
-template <bool BVH, bool SHARE = false>
+template <bool BVH, int SHARE = 0>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in,
                                                                 int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh 
         const size_t i = region + (live ? base + lane : 0u);
         ProbeHead h;
         load_probe_head(b, i, h);
-        const bool blocked = SHARE ? shadow_any_hit_shared(sc, bv, h.probe, h.max_t, h.current, live, ws, share, bc)
+        const bool blocked = SHARE ? shadow_any_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, h.probe, h.max_t, h.current, live, ws, share, bc)
                              : BVH ? shadow_any_hit_bvh(sc, bv, h.probe, h.max_t, h.current, live, ws, bc)
                                  : shadow_any_hit_bf(sc, h.probe, h.max_t, h.current, live);
         PathState ps;
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh 
 }
 
 // Glossy-probe stage: search of sampleLightGlossy (raytracer.glsl:403-437), then :557-579.
-template <bool BVH, bool SHARE = false>
+template <bool BVH, int SHARE = 0>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
                                                                 int depth, int q_in, int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
         load_probe_head(b, i, h);
         int light_id;
         f4 lsec;
-        const int outcome = SHARE ? glossy_search_shared(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, share, bc)
+        const int outcome = SHARE ? glossy_search_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, share, bc)
                             : BVH ? glossy_search_bvh(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, bc)
                                 : glossy_search_bf(sc, h.probe, h.current, live, light_id, lsec);
         PathState ps;
@@ -1448,6 +1448,8 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
     const bool use_bvh = bvh.enabled != 0;
     // lane refill needs the hierarchy; it shades depth >= 1 in a kernel of its own
     const bool use_refill = use_bvh && refill && fused;
+    // shared any-hit searches: with a node budget per round where traversals are long
+    const int share_mode = !(use_bvh && share) ? 0 : (sc.count >= SHARE_BUDGET_MIN_TRIANGLES ? 2 : 1);
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
     const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
     const uint32_t pps = tiles * 64u;
@@ -1500,8 +1502,10 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
             if (use_bvh && pool && buf.region_cap >= POOL_MIN_REGION)
                 hipLaunchKernelGGL(k_first_pool, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins, pps,
                                    (uint32_t)n, max_depth);
-            else if (use_bvh && share) hipLaunchKernelGGL((k_first<true, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf,
-                                                          d_samples, d_coins, pps, (uint32_t)n, max_depth);
+            else if (use_bvh && share_mode == 2) hipLaunchKernelGGL((k_first<true, 2>), grid, block, 0, stream, sc, bvh, light_bvh, fr,
+                                                                    buf, d_samples, d_coins, pps, (uint32_t)n, max_depth);
+            else if (use_bvh && share_mode == 1) hipLaunchKernelGGL((k_first<true, 1>), grid, block, 0, stream, sc, bvh, light_bvh, fr,
+                                                                    buf, d_samples, d_coins, pps, (uint32_t)n, max_depth);
             else if (use_bvh) hipLaunchKernelGGL(k_first<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins,
                                                  pps, (uint32_t)n, max_depth);
             else hipLaunchKernelGGL(k_first<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins,
@@ -1513,10 +1517,16 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         }
         if (use_bvh && fused && depth > 0 && depth <= inplace_depths) {
             // this bounce with its probes in place, as at depth 0
-            if (share) hipLaunchKernelGGL((k_tail<true, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
-                                          d_coins, pps, max_depth);
-            else hipLaunchKernelGGL((k_tail<true, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
-                                    d_coins, pps, max_depth);
+#define LAUNCH_TAIL(ONE_, DEPTH_)                                                                                            \
+    do {                                                                                                                     \
+        if (share_mode == 2) hipLaunchKernelGGL((k_tail<ONE_, 2>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, DEPTH_, q_in, \
+                                                d_coins, pps, max_depth);                                                    \
+        else if (share_mode == 1) hipLaunchKernelGGL((k_tail<ONE_, 1>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, DEPTH_, \
+                                                     q_in, d_coins, pps, max_depth);                                         \
+        else hipLaunchKernelGGL((k_tail<ONE_, 0>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, DEPTH_, q_in, d_coins, pps,  \
+                                max_depth);                                                                                  \
+    } while (0)
+            LAUNCH_TAIL(true, depth);
             PIPE_TRY(hipGetLastError());
             PIPE_TRY(stamp(-1));
             q_in ^= 1;
@@ -1550,11 +1560,14 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         PIPE_TRY(stamp(1));
         if (use_refill && !share) {      // shared any-hit searches beat refilled ones (1 M triangles: 8.3 vs 11.1 ms)
             hipLaunchKernelGGL(k_probe_refill, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
-        } else if (use_bvh && share) {
-            hipLaunchKernelGGL((k_probe_shadow<true, true>), grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
+        } else if (use_bvh && share_mode == 2) {
+            hipLaunchKernelGGL((k_probe_shadow<true, 2>), grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
             PIPE_TRY(hipGetLastError());
-            hipLaunchKernelGGL((k_probe_glossy<true, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in,
-                               max_depth);
+            hipLaunchKernelGGL((k_probe_glossy<true, 2>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
+        } else if (use_bvh && share_mode == 1) {
+            hipLaunchKernelGGL((k_probe_shadow<true, 1>), grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
+            PIPE_TRY(hipGetLastError());
+            hipLaunchKernelGGL((k_probe_glossy<true, 1>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
         } else if (use_bvh) {
             hipLaunchKernelGGL(k_probe_shadow<true>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
             PIPE_TRY(hipGetLastError());
@@ -1578,10 +1591,7 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
             if (h_count[0] == 0) break;
             if (use_tail && (size_t)h_count[0] * (size_t)tail_div <= paths) {
                 PIPE_TRY(stamp(0));
-                if (share) hipLaunchKernelGGL((k_tail<false, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth + 1,
-                                              q_in, d_coins, pps, max_depth);
-                else hipLaunchKernelGGL((k_tail<false, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth + 1,
-                                        q_in, d_coins, pps, max_depth);
+                LAUNCH_TAIL(false, depth + 1);
                 PIPE_TRY(hipGetLastError());
                 PIPE_TRY(stamp(-1));
                 break;
