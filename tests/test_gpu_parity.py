@@ -226,10 +226,57 @@ def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
     sc.upload_env(gradient_env())
     cam = camera_matrix((0.0, 1.0, -2.0), (-0.3, 0.0))
     want, wst = sc.render(cam, DEFAULT_CLOCK, 16, 1.0, 32, 24, 0, 3)
-    for pipeline in (0, 1, 2, 3, 4):
+    for pipeline in (0, 1, 2, 3, 4, 7, 8, 9, 10):
         img, st = _render(gpu_ctx, 32, 24, 0, 3, recursion=16, pipeline=pipeline, batch=2, cam=cam)
         assert np.array_equal(img, want, equal_nan=True), pipeline
         assert st["rays"] == wst["rays"] and st["glossy_probes"] == wst["glossy_probes"]
+
+
+def test_call_sequences(oracle_mod, cubes, obiwan):
+    # State carried between calls: many small passes back to back without synchronising (the per-pass tables are
+    # staged through two pinned slots), a change of resolution, of scene and of frame parameters in between, and
+    # two contexts used in turn.
+    import gpuraytracer_amd as g
+    env = constant_env()
+    oc = oracle_mod.OracleScene(*cubes)
+    oc.upload_env(env)
+    oo = oracle_mod.OracleScene(*obiwan)
+    oo.upload_env(env)
+    a, b = g.Context(0), g.Context(0)
+    try:
+        for ctx in (a, b):
+            ctx.set_option("batch_samples", 1)
+        a.upload_scene(*cubes); a.upload_env(env)
+        b.upload_scene(*obiwan); b.upload_env(env)
+        a.resize(40, 24); b.resize(24, 40)
+        a.set_frame(CAM, DEFAULT_CLOCK, 6, 1.0)
+        b.set_frame(CAM, 4242, 9, 1.0)
+        for k in range(12):                      # 12 passes of one sample each, alternating contexts, no sync
+            a.trace(k, 1, 1)
+            b.trace(2 * k, 1, 2)
+        img_a, n_a = a.read_sum()
+        img_b, n_b = b.read_sum()
+        want_a, _ = oc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 40, 24, 0, 12)
+        want_b, _ = oo.render(CAM, 4242, 9, 1.0, 24, 40, 0, 12, 2)
+        assert n_a == 12 and n_b == 12
+        assert np.array_equal(img_a, want_a) and np.array_equal(img_b, want_b, equal_nan=True)
+        # new size, new frame, larger passes on the same context; then another scene on it
+        a.set_option("batch_samples", 5)
+        a.resize(56, 16)
+        a.set_frame(CAM, 99, 4, 1.0)
+        a.trace(3, 7, 1)
+        img, n = a.read_sum()
+        want, _ = oc.render(CAM, 99, 4, 1.0, 56, 16, 3, 7)
+        assert n == 7 and np.array_equal(img, want)
+        a.upload_scene(*obiwan)
+        a.resize(56, 16)
+        a.trace(0, 3, 1)
+        img, n = a.read_sum()
+        want, _ = oo.render(CAM, 99, 4, 1.0, 56, 16, 0, 3)
+        assert n == 3 and np.array_equal(img, want, equal_nan=True)
+    finally:
+        a.close()
+        b.close()
 
 
 def test_box_scene_without_lights(gpu_ctx, oracle_mod):
