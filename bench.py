@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--pool", type=int, default=-1, help="-1 library default, 0/1 depth 0 without/with the workgroup probe pool")
     ap.add_argument("--first-in-place", type=int, default=-1, help="-1 library default, 0/1 depth 0 through the queues / in one kernel")
     ap.add_argument("--inplace-depths", type=int, default=-1, help="-1 library default; bounces after the first with probes in place")
+    ap.add_argument("--share-closest", type=int, default=-1, help="-1 library default; 0/1 closest-hit searches of deeper bounces shared")
     ap.add_argument("--share", type=int, default=-1, help="-1 library default; 0/1 depth-0 any-hit searches shared among the lanes of a wave")
     ap.add_argument("--tail", type=int, default=-1, help="-1 library default; 0 no tail kernel, n: once at most 1/n of the batch is left")
     ap.add_argument("--lane-utilisation", action="store_true",
@@ -157,6 +158,8 @@ def main():
         ctx.set_option("pool", args.pool)
     if args.inplace_depths >= 0:
         ctx.set_option("inplace_depths", args.inplace_depths)
+    if args.share_closest >= 0:
+        ctx.set_option("share_closest", args.share_closest)
     if args.share >= 0:
         ctx.set_option("share", args.share)
     if args.tail >= 0:

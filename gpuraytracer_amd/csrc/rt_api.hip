@@ -67,6 +67,7 @@ struct rt_context {
     int profiling = 0;
     int fuse_shade = 1;
     int first_in_place = 1;    // depth 0 in one kernel with the probes in place (k_first); 0: depth 0 through the queues
+    int share_closest = 0;     // deeper bounces: the closest-hit searches are shared as well (closest_hit_shared)
     int share = 1;             // lanes of a wave share the any-hit searches of its probes (anyhit_shared)
     int inplace_depths = 0;    // bounces after the first that also run their probes in place
     int tail = 64;             // the tail kernel takes over once at most 1/tail of a batch's paths is left (0: never)
@@ -591,7 +592,7 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
                                          ctx->d_sum, ctx->d_samples, (int)n, ctx->stream, ctx->profiling != 0,
                                          ctx->fuse_shade != 0,
                                          ctx->refill < 0 ? ctx->count >= REFILL_AUTO_MIN : ctx->refill != 0,
-                                         ctx->pool != 0, ctx->first_in_place != 0, ctx->tail, ctx->inplace_depths, ctx->share != 0,
+                                         ctx->pool != 0, ctx->first_in_place != 0, ctx->tail, ctx->inplace_depths, ctx->share != 0, ctx->share_closest != 0,
                                          &ctx->host_stats, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
@@ -769,6 +770,8 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "tonemap")) {
         if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "tonemap must be 0 or 1");
         ctx->tonemap = (int)value;
+    } else if (!strcmp(name, "share_closest")) {
+        ctx->share_closest = value ? 1 : 0;
     } else if (!strcmp(name, "share")) {
         ctx->share = value ? 1 : 0;
     } else if (!strcmp(name, "inplace_depths")) {

@@ -363,6 +363,109 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const BvhScratch &ws, lds_u8_ptr scrat
     return flags[lane] != 0;
 }
 
+// Closest-hit search in which the lanes of a wave share the work.  The closest hit is the fold of rule 3 over the
+// candidates of all subtrees, and that fold does not depend on the order for up to two candidates near the closest
+// depth (more make the lane redo the index-order loop, as in closest_hit_bvh).  So, as in anyhit_shared, a lane
+// without work takes the newest stack entry of a busy lane together with its ray, folds the candidates of that
+// subtree, and hands the partial fold back: it puts its lane number into the owner's one-byte mailbox in LDS, and
+// the owner pulls the fold through ds_bpermute and merges it into its own.  Partial folds prune with the depth
+// known when the subtree changed hands, which is looser than the sequential search's, never tighter.
+// Merging near-candidate counts adds the counts of the partial folds whose depth lies within the margin of the
+// merged one; that can over-count (more redos), never under-count.
+RT_DEV void closest_fold_merge(ClosestFold &r, const ClosestFold &w) {
+    if (w.best < 0) return;
+    bool take;
+    if (r.best < 0) take = true;
+    else if (w.best > r.best) take = !(w.st.z * r.st.w > r.st.z * w.st.w);
+    else take = (r.st.z * w.st.w > w.st.z * r.st.w);
+    const float g = __builtin_fminf(r.t_min, w.t_min);
+    const int n = ((r.t_min <= g * BVH_NEAR) ? r.n_near : 0) + ((w.t_min <= g * BVH_NEAR) ? w.n_near : 0);
+    r.t_min = g;
+    r.n_near = n;
+    if (take) { r.best = w.best; r.st = w.st; }
+}
+
+template <int NODE_BUDGET>
+RT_DEV int closest_hit_shared(const DScene &sc, const DBvh &bv, const Ray &ray_in, bool active, int begin_id, int end_id,
+                              int current_in, float w_init, const BvhScratch &ws, lds_u8_ptr scratch, f4 &isec,
+                              BvhCounters &cnt) {
+    const int lane = (int)(threadIdx.x & 63u);
+    lds_u8_ptr mail = scratch, table = scratch + 64;
+    Ray ray = ray_in;
+    int current = current_in, owner = lane;
+    BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    const bool own_finite = br.finite;
+    ClosestFold res, job;            // res: the fold of this lane's own query; job: of the subtree being searched now
+    closest_fold_reset(res, w_init);
+    closest_fold_reset(job, w_init);
+    float bound = __builtin_inff();  // depth beyond which nothing can matter to the job's owner
+    bool busy = active && br.finite;
+    TravState ts;
+    ts.node = 0; ts.sp = 0; ts.run = busy;
+    auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ray, slot, begin_id, end_id, current, job); return true; };
+    auto limit = [&]() -> float { return __builtin_fminf(job.t_min, bound) * BVH_NEAR; };
+    for (;;) {
+        // jobs that have ended: an own one is merged here, a helper's fold goes to its owner
+        const bool ended = busy && !ts.run;
+        if (ended && owner == lane) { closest_fold_merge(res, job); busy = false; }
+        bool want = ended && owner != lane;
+        if (want && job.best < 0) { want = false; busy = false; }
+        while (__builtin_amdgcn_ballot_w64(want) != 0ull) {
+            mail[lane] = 0xFF;
+            if (want) mail[owner] = (unsigned char)lane;           // one sender per owner and turn: the last writer
+            const int sender = (int)mail[lane];
+            const bool has = sender != 0xFF;
+            const int from4 = 4 * (has ? sender : lane);
+            ClosestFold in;
+            in.best = __builtin_amdgcn_ds_bpermute(from4, job.best);
+            in.n_near = __builtin_amdgcn_ds_bpermute(from4, job.n_near);
+            in.t_min = lane_read(job.t_min, from4);
+            in.st.x = lane_read(job.st.x, from4); in.st.y = lane_read(job.st.y, from4);
+            in.st.z = lane_read(job.st.z, from4); in.st.w = lane_read(job.st.w, from4);
+            if (has) closest_fold_merge(res, in);
+            if (want && (int)mail[owner] == lane) { want = false; busy = false; }
+        }
+        if (busy && owner == lane) bound = res.t_min;               // what helpers have found prunes the own search
+        const unsigned long long running = __builtin_amdgcn_ballot_w64(ts.run);
+        if (running == 0ull) break;
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+        const unsigned long long donors = __builtin_amdgcn_ballot_w64(ts.run && ts.sp > 0);
+        const int n_idle = (int)__popcll(idle), n_donors = (int)__popcll(donors);
+        if (n_idle >= SHARE_MIN_IDLE && n_donors > 0) {
+            const int n_take = n_idle < n_donors ? n_idle : n_donors;
+            const int d_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
+            const int i_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const bool gives = ts.run && ts.sp > 0 && d_rank < n_take;
+            const bool takes = !busy && i_rank < n_take;
+            if (gives) table[d_rank] = (unsigned char)lane;
+            int given = 0;
+            if (gives) { ts.sp--; given = ws.stack[64 * ts.sp]; }
+            const int from4 = takes ? 4 * (int)table[i_rank] : 4 * lane;
+            const int t_node = __builtin_amdgcn_ds_bpermute(from4, given);
+            const int t_owner = __builtin_amdgcn_ds_bpermute(from4, owner);
+            const int t_current = __builtin_amdgcn_ds_bpermute(from4, current);
+            const float t_bound = lane_read(__builtin_fminf(job.t_min, bound), from4);
+            Ray r2; BvhRay b2;
+            r2.o = mk3(lane_read(ray.o.x, from4), lane_read(ray.o.y, from4), lane_read(ray.o.z, from4));
+            r2.d = mk3(lane_read(ray.d.x, from4), lane_read(ray.d.y, from4), lane_read(ray.d.z, from4));
+            b2.inv = mk3(lane_read(br.inv.x, from4), lane_read(br.inv.y, from4), lane_read(br.inv.z, from4));
+            b2.oi_lo = mk3(lane_read(br.oi_lo.x, from4), lane_read(br.oi_lo.y, from4), lane_read(br.oi_lo.z, from4));
+            b2.oi_hi = mk3(lane_read(br.oi_hi.x, from4), lane_read(br.oi_hi.y, from4), lane_read(br.oi_hi.z, from4));
+            if (takes) {
+                ray = r2; br.inv = b2.inv; br.oi_lo = b2.oi_lo; br.oi_hi = b2.oi_hi;
+                owner = t_owner; current = t_current; bound = t_bound;
+                closest_fold_reset(job, w_init);
+                ts.node = t_node; ts.sp = 0; ts.run = true;
+                busy = true;
+            }
+        }
+        bvh_advance<(NODE_BUDGET > 0)>(bv, br, ws, ts, SHARE_MIN_IDLE, leaf, limit, cnt, true, NODE_BUDGET > 0 ? NODE_BUDGET : 1 << 30);
+    }
+    closest_fold_redo(sc, ray_in, active && (!own_finite || res.n_near > 2), begin_id, end_id, current_in, w_init, res);
+    isec = res.st;
+    return res.best;
+}
+
 // sampleLight's occlusion query (raytracer.glsl:372-378): is any triangle != current hit by
 // intersectTriangleShadow within max_t?
 RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,

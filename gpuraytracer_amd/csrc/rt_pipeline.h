@@ -216,7 +216,7 @@ RT_DEV bool first_path(const DFrame &fr, const uint32_t *__restrict__ samples, u
 // pixels itself instead of reading a queue.  FUSED: the wave goes on to shade its paths; otherwise it
 // writes the hit record h0 = (u, v, t, triangle id; -1 = miss) and k_shade does the shading.  BVH:
 // hierarchy traversal instead of the loop over all triangles.
-template <bool FIRST, bool FUSED, bool BVH>
+template <bool FIRST, bool FUSED, bool BVH, int SHARE = 0>
 __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
                                                           const uint32_t *__restrict__ samples,
                                                           const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
@@ -231,6 +231,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
     ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
     ws.top = (lds_v4f_ptr)top_mem;
     ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
+    __shared__ unsigned char share_mem[SHARE ? 128 * WG_WAVES : 1];
+    lds_u8_ptr share = (lds_u8_ptr)share_mem + (SHARE ? 128 * (threadIdx.x >> 6) : 0);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     uint32_t n_paths = 0, n_rays = 0;
@@ -258,7 +260,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
         n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
-        const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, isec, bc)
+        const int hit = SHARE ? closest_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, share, isec, bc)
+                        : BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, isec, bc)
                             : closest_hit_bf(sc, ray, isec);
         const float inv_det = 1.0f / isec.w;
         if (FUSED) {
@@ -1439,12 +1442,14 @@ struct Pipeline {
     // Renders the `n` samples listed in d_samples and adds them to `sum`.
     hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                    const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                   bool pool, bool in_place, int tail_div, int inplace_depths, bool share, rt_stats *host_stats, const char **what);
+                   bool pool, bool in_place, int tail_div, int inplace_depths, bool share, bool share_closest, rt_stats *host_stats,
+                   const char **what);
 };
 
 inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                                 const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                                bool pool, bool in_place, int tail_div, int inplace_depths, bool share, rt_stats *host_stats, const char **what) {
+                                bool pool, bool in_place, int tail_div, int inplace_depths, bool share, bool share_closest, rt_stats *host_stats,
+                                const char **what) {
     const bool use_bvh = bvh.enabled != 0;
     // lane refill needs the hierarchy; it shades depth >= 1 in a kernel of its own
     const bool use_refill = use_bvh && refill && fused;
@@ -1541,6 +1546,12 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
             PIPE_TRY(hipGetLastError());
         } else if (fused) {
             if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, true, true); else LAUNCH_EXTEND(true, true, false); }
+            else if (use_bvh && share_closest && share_mode == 2)
+                hipLaunchKernelGGL((k_extend<false, true, true, 2>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples,
+                                   d_coins, pps, (uint32_t)n, max_depth);
+            else if (use_bvh && share_closest && share_mode == 1)
+                hipLaunchKernelGGL((k_extend<false, true, true, 1>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples,
+                                   d_coins, pps, (uint32_t)n, max_depth);
             else { if (use_bvh) LAUNCH_EXTEND(false, true, true); else LAUNCH_EXTEND(false, true, false); }
             PIPE_TRY(hipGetLastError());
         } else {

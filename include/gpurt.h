@@ -189,6 +189,8 @@ int rt_reset_stats(rt_context *ctx);
  *   "share"         1 = the lanes of a wave share the any-hit searches of its light probes: an idle lane takes a
  *                   subtree off the stack of a busy one (default; needs the hierarchy), 0 = every lane searches
  *                   alone; results are identical
+ *   "share_closest" 1 = the closest-hit searches of the bounces after the first are shared in the same way
+ *                   (default 0: no gain measured); results are identical
  *   "inplace_depths" n: the n bounces after the first also run their light probes in place instead of through
  *                   the probe queues (default 0: 1 % slower when on); results are identical
  *   "first_in_place" 1 = depth 0 runs in one kernel and its light probes run in place (default, faster),

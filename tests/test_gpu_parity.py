@@ -30,7 +30,8 @@ def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK,
     # 6 = staged, hierarchy, depth 0 through the queues like the deeper bounces, 7 = staged, hierarchy, no tail kernel
     # (1 hands the last paths of a pass to the tail kernel as soon as at most 1/64 of them is left), 8 = the tail
     # kernel takes whatever is left after the third bounce, 9 = the second and third bounce also run their probes in place,
-    # 10 = every lane runs its own any-hit search (1: the lanes of a wave share them)
+    # 10 = every lane runs its own any-hit search (1: the lanes of a wave share them), 11 = the closest-hit searches
+    # of the deeper bounces are shared as well
     ctx.set_option("fuse_shade", 0 if pipeline == 2 else 1)
     ctx.set_option("accel", 0 if pipeline == 3 else 1)
     ctx.set_option("refill", 1 if pipeline == 4 else 0)
@@ -39,6 +40,7 @@ def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK,
     ctx.set_option("tail", 0 if pipeline == 7 else (1 if pipeline == 8 else 64))
     ctx.set_option("inplace_depths", 2 if pipeline == 9 else 0)
     ctx.set_option("share", 0 if pipeline == 10 else 1)
+    ctx.set_option("share_closest", 1 if pipeline == 11 else 0)
     pipeline = min(pipeline, 1)
     ctx.set_option("pipeline", pipeline)
     ctx.set_option("batch_samples", batch)
@@ -122,7 +124,7 @@ def test_hierarchy_equals_index_order_loop(gpu_ctx, name):
 REF_IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close"]
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("case", REF_IMAGE_CASES)
 def test_images_equal_reference_shader(gpu_ctx, case, pipeline):
     """Images the reference's main() wrote for single SAMPLE values, bit for bit.  The reference stores
@@ -171,7 +173,7 @@ def test_mean_equals_reference_running_mean(gpu_ctx):
     assert np.allclose(total / 16.0, want, rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
     _upload(gpu_ctx, cubes, constant_env())
     for spp in (1, 4, 16):
@@ -181,7 +183,7 @@ def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
         assert [st["pixel_samples"], st["rays"], st["shadow_probes"], st["glossy_probes"]] == g["stats"].tolist()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_image_vs_checker_gradient_env_ragged(gpu_ctx, oracle_mod, cubes, pipeline):
     # 52 x 37 is not a multiple of the 8 x 8 tile; the gradient environment exercises the bilinear lookup
     _upload(gpu_ctx, cubes, gradient_env())
@@ -226,7 +228,7 @@ def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
     sc.upload_env(gradient_env())
     cam = camera_matrix((0.0, 1.0, -2.0), (-0.3, 0.0))
     want, wst = sc.render(cam, DEFAULT_CLOCK, 16, 1.0, 32, 24, 0, 3)
-    for pipeline in (0, 1, 2, 3, 4, 7, 8, 9, 10):
+    for pipeline in (0, 1, 2, 3, 4, 7, 8, 9, 10, 11):
         img, st = _render(gpu_ctx, 32, 24, 0, 3, recursion=16, pipeline=pipeline, batch=2, cam=cam)
         assert np.array_equal(img, want, equal_nan=True), pipeline
         assert st["rays"] == wst["rays"] and st["glossy_probes"] == wst["glossy_probes"]
