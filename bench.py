@@ -121,11 +121,15 @@ def main():
     ap.add_argument("--share-closest", type=int, default=-1, help="-1 library default; 0/1 closest-hit searches of deeper bounces shared")
     ap.add_argument("--share", type=int, default=-1, help="-1 library default; 0/1 depth-0 any-hit searches shared among the lanes of a wave")
     ap.add_argument("--tail", type=int, default=-1, help="-1 library default; 0 no tail kernel, n: once at most 1/n of the batch is left")
+    ap.add_argument("--width", type=int, default=1920, help="target width (the headline metric is quoted at 1920 x 1080)")
+    ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lane-utilisation", action="store_true",
                     help="cubes/obiwan: add the lane utilisation of the traversal loops (two extra 32 spp renders in child processes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
+    global W, H
+    W, H = args.width, args.height
 
     import torch
     import gpuraytracer_amd as g
@@ -266,7 +270,7 @@ def main():
                      "probe_kernels_ms": st["probe_ms"], "extend_kernels_ms": st["extend_ms"],
                      "shade_kernels_ms": st["shade_ms"]})
         out = {
-            "metric": "Mrays/s (paths x bounces) at 1080p",
+            "metric": "Mrays/s (paths x bounces) at 1080p" if (W, H) == (1920, 1080) else "Mrays/s (paths x bounces) at %dx%d" % (W, H),
             "value": rays / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,8 +280,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s, 1920x1080, RECURSION %d, %d spp per GPU (%d spp/step), "
-                                   "constant environment" % (workload_name, RECURSION, args.steps * spp, spp),
+            "config": {"workload": "%s, %dx%d, RECURSION %d, %d spp per GPU (%d spp/step), "
+                                   "constant environment" % (workload_name, W, H, RECURSION, args.steps * spp, spp),
                        "pipeline": "staged" if args.pipeline else "single-kernel",
                        "closest_hit": "hierarchy (exact)" if used_bvh else "loop over all triangles",
                        "parallelism": "spp split x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
