@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=64)
-    ap.add_argument("--batch-samples", type=int, default=32)
+    ap.add_argument("--batch-samples", type=int, default=64, help="samples per pass (about 320 bytes of queue memory per pixel-sample of a pass: 42 GB at 1080p)")
     ap.add_argument("--pipeline", type=int, default=1)
     ap.add_argument("--fuse-shade", type=int, default=1)
     ap.add_argument("--accel", type=int, default=-1, help="-1 auto, 0 loops over all triangles, 1 hierarchy")

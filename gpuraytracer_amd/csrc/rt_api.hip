@@ -63,7 +63,7 @@ struct rt_context {
 
     // options
     int pipeline = 1;
-    int batch_samples = 16;
+    int batch_samples = 32;
     int profiling = 0;
     int fuse_shade = 1;
     int first_in_place = 1;    // depth 0 in one kernel with the probes in place (k_first); 0: depth 0 through the queues
@@ -758,7 +758,7 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
         if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "pipeline must be 0 or 1");
         ctx->pipeline = (int)value;
     } else if (!strcmp(name, "batch_samples")) {
-        if (value < 1 || value > 64) return fail(ctx, RT_ERR_LIMIT, "batch_samples must be in [1, 64]");
+        if (value < 1 || value > 256) return fail(ctx, RT_ERR_LIMIT, "batch_samples must be in [1, 256]");
         ctx->batch_samples = (int)value;
     } else if (!strcmp(name, "accel")) {
         if (value < -1 || value > 1) return fail(ctx, RT_ERR_INVALID, "accel must be -1 (auto), 0 or 1");

@@ -174,7 +174,7 @@ int rt_reset_stats(rt_context *ctx);
 /* Tuning knobs; unknown names return RT_ERR_INVALID.
  *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
  *                   1 = staged kernels over compacted ray queues (default)
- *   "batch_samples" samples rendered per pass of the staged pipeline (default 16; about 320 bytes of
+ *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 256; about 320 bytes of
  *                   device memory per pixel and sample of a pass)
  *   "accel"         -1 = bounding-volume hierarchy for scenes of 64 triangles or more (default),
  *                   0 = the reference's loops over all triangles, 1 = hierarchy always; results are identical

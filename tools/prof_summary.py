@@ -6,7 +6,7 @@ import collections, csv, glob, json, sys
 tag = sys.argv[1]
 base = "gpurun_out/prof_" + tag
 out = ["# rocprofv3 summary '%s': python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bruteforce-pass\n"
-       "# (cubes, 1920x1080, RECURSION 6; 3 x 64 spp in batches of 32 spp: 6 launches of the depth-0 kernel)\n" % tag]
+       "# (cubes, 1920x1080, RECURSION 6; 3 x 64 spp, one pass of 64 spp each: 3 launches of the depth-0 kernel)\n" % tag]
 rows = list(csv.DictReader(open(glob.glob(base + "/trace/vm/*_kernel_stats.csv")[0])))
 out.append("\n## kernel stats (--kernel-trace --stats)\n%-44s %6s %14s %12s %7s\n" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows:
