@@ -720,74 +720,100 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
     const int depth_end = ONE ? (depth0 + 1 < max_depth ? depth0 + 1 : max_depth) : max_depth;
     const uint32_t total = b.n_ext[q_in][wave];
     const size_t region = (size_t)wave * b.region_cap;
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const bool live = base + lane < total;
-        PathState ps;
-        uint32_t id = 0, kept_flags = 0;
-        load_path_rec(b, q_in, region + (live ? base + lane : 0u), ps, id, kept_flags);
+    // per-lane state of the path a lane is walking
+    PathState ps;
+    uint32_t id = 0, kept_flags = 0, coin_row = 0;
+    bool alive = false;
+    ps.o = ps.d = ps.path = ps.energy = ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
+    ps.seed = 0;
+    auto take_record = [&](uint32_t pos) {
+        load_path_rec(b, q_in, region + pos, ps, id, kept_flags);
         ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
-        if (live && (kept_flags & KEPT_DIFF)) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
-        if (live && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
-        const uint32_t coin_row = (live ? id / paths_per_sample : 0u) * (uint32_t)max_depth;
-        bool alive = live;
-        for (int depth = depth0; depth < depth_end; depth++) {
-            if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
-            n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(alive));
-            Ray ray; ray.o = ps.o; ray.d = ps.d;
-            f4 isec;
-            const int hit = closest_hit_bvh(sc, bv, ray, alive, 0, sc.count, -1, 1.0f, ws, isec, bc);
-            const float inv_det = 1.0f / isec.w;
-            const bool coin_diffuse = coins[coin_row + (uint32_t)depth] != 0u;
-            Bounce bn;
-            bn.kind = PROBE_NONE; bn.max_t = 0.0f; bn.w = 0.0f; bn.roughness = 0.0f;
-            bn.c = bn.lit = bn.albedo = bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
-            bool shaded = false;
-            if (alive) {
-                if (hit < 0) {
-                    ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
-                } else {
-                    shade_pre(sc, fr, ps, hit, isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, coin_diffuse, bn);
-                    shaded = true;
-                }
+        if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
+        if (kept_flags & KEPT_SPEC) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
+        coin_row = (id / paths_per_sample) * (uint32_t)max_depth;
+    };
+    // one bounce of every lane with `alive`, each at its own `depth`
+    auto bounce = [&](int depth) {
+        n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(alive));
+        Ray ray; ray.o = ps.o; ray.d = ps.d;
+        f4 isec;
+        const int hit = closest_hit_bvh(sc, bv, ray, alive, 0, sc.count, -1, 1.0f, ws, isec, bc);
+        const float inv_det = 1.0f / isec.w;
+        const bool coin_diffuse = coins[alive ? coin_row + (uint32_t)depth : 0u] != 0u;     // idle lanes: any valid entry
+        Bounce bn;
+        bn.kind = PROBE_NONE; bn.max_t = 0.0f; bn.w = 0.0f; bn.roughness = 0.0f;
+        bn.c = bn.lit = bn.albedo = bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
+        bool shaded = false;
+        if (alive) {
+            if (hit < 0) {
+                ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
+            } else {
+                shade_pre(sc, fr, ps, hit, isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, coin_diffuse, bn);
+                shaded = true;
             }
-            Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
-            const bool run_s = shaded && coin_diffuse && bn.kind == PROBE_SHADOW;
-            const bool run_g = shaded && !coin_diffuse && bn.kind == PROBE_GLOSSY;
-            bool blocked = true;
-            if (__builtin_amdgcn_ballot_w64(run_s) != 0ull) {
-                blocked = SHARE ? shadow_any_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, probe, bn.max_t, hit, run_s, ws, share, pc)
-                                : shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run_s, ws, pc);
-                n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_s));
-            }
-            int outcome = 0, light_id = -1;
-            f4 lsec;
-            lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
-            if (__builtin_amdgcn_ballot_w64(run_g) != 0ull) {
-                outcome = SHARE ? glossy_search_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, share, pc)
-                                : glossy_search_bvh(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, pc);
-                n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_g));
-            }
-            bool go_on = false;
-            if (shaded) {
-                if (coin_diffuse) {
-                    const bool written = run_s && !blocked;
-                    go_on = finish_diffuse(sc, ps, hit, written, bn.lit, bn.albedo, bn.roughness);
-                    if (ONE && written) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
-                } else {
-                    go_on = finish_glossy(sc, fr, ps, hit, run_g ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
-                    if (ONE && run_g && outcome != 0) {
-                        b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
-                        kept_flags |= KEPT_SPEC;
-                    }
-                }
-            }
-            go_on = go_on && (depth + 1 < max_depth);
-            if (alive && !go_on) finish_path(b, id, ps);
-            alive = alive && go_on;
         }
-        if (ONE) {      // whole waves: the queue position comes from a ballot
+        Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
+        const bool run_s = shaded && coin_diffuse && bn.kind == PROBE_SHADOW;
+        const bool run_g = shaded && !coin_diffuse && bn.kind == PROBE_GLOSSY;
+        bool blocked = true;
+        if (__builtin_amdgcn_ballot_w64(run_s) != 0ull) {
+            blocked = SHARE ? shadow_any_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, probe, bn.max_t, hit, run_s, ws, share, pc)
+                            : shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run_s, ws, pc);
+            n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_s));
+        }
+        int outcome = 0, light_id = -1;
+        f4 lsec;
+        lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
+        if (__builtin_amdgcn_ballot_w64(run_g) != 0ull) {
+            outcome = SHARE ? glossy_search_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, share, pc)
+                            : glossy_search_bvh(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, pc);
+            n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_g));
+        }
+        bool go_on = false;
+        if (shaded) {
+            if (coin_diffuse) {
+                const bool written = run_s && !blocked;
+                go_on = finish_diffuse(sc, ps, hit, written, bn.lit, bn.albedo, bn.roughness);
+                if (ONE && written) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
+            } else {
+                go_on = finish_glossy(sc, fr, ps, hit, run_g ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
+                if (ONE && run_g && outcome != 0) {
+                    b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
+                    kept_flags |= KEPT_SPEC;
+                }
+            }
+        }
+        go_on = go_on && (depth + 1 < max_depth);
+        if (alive && !go_on) finish_path(b, id, ps);
+        alive = alive && go_on;
+    };
+    if (ONE) {
+        for (uint32_t base = 0; base < total; base += 64u) {
+            alive = base + lane < total;
+            if (alive) take_record(base + lane);
+            if (depth0 < depth_end) bounce(depth0);
+            // whole waves: the queue position comes from a ballot
             const uint32_t slot = region_slot(fill_next, alive);
             if (alive) store_path_rec(b, q_in ^ 1, region + slot, ps, id, kept_flags);
+        }
+    } else {
+        // Lanes whose path has ended take the next record of the region, so the wave stays full while lanes are at
+        // different depths of different paths.
+        uint32_t next = 0;
+        int depth = depth0;
+        for (;;) {
+            const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
+            if (next < total && idle != 0ull) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t avail = total - next, n_idle = (uint32_t)__popcll(idle);
+                const uint32_t take = n_idle < avail ? n_idle : avail;
+                if (!alive && rank < take) { take_record(next + rank); depth = depth0; alive = depth0 < max_depth; }
+                next += take;
+            }
+            if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+            bounce(depth);
+            depth++;
         }
     }
     if (lane == 0) {
