@@ -691,8 +691,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_first_pool(DScene sc, DBvh
 // the record count: 45-60 us per kernel plus launch gaps and the early-stop read-back, three kernels per depth
 // (12 depths of that are a fifth of a RECURSION 16 batch).  Here every lane walks the rest of its path: closest
 // hit, shading, probe in place, rest of the bounce, next bounce, as in the single-kernel form but starting from
-// the records of the extend queue and with the hierarchy.  Lanes of a wave end at different depths, which does
-// not matter for so few paths; the kept light results stay in registers.
+// the records of the extend queue and with the hierarchy.  Lanes of a wave end at different depths; a lane whose
+// path has ended takes the next record of the wave's region, so every bounce runs with a full wave until the
+// region is used up.  The kept light results stay in registers.
 #ifndef RT_TAIL_FIRST_CHECK
 #define RT_TAIL_FIRST_CHECK 2     // the host first looks at the queue size after this depth
 #endif
