@@ -281,6 +281,19 @@ def test_call_sequences(oracle_mod, cubes, obiwan):
         b.close()
 
 
+@pytest.mark.parametrize("w,h,recursion,count", [(1, 1, 6, 3), (9, 3, 1, 2), (8, 8, 2, 1), (65, 7, 6, 70), (3, 130, 40, 2)])
+def test_edge_sizes(gpu_ctx, oracle_mod, cubes, w, h, recursion, count):
+    # a single pixel, targets smaller than a tile, RECURSION 1, more samples than fit one pass, RECURSION 40
+    env = gradient_env()
+    _upload(gpu_ctx, cubes, env)
+    sc = oracle_mod.OracleScene(*cubes)
+    sc.upload_env(env)
+    want, wst = sc.render(CAM, 5, recursion, 1.0, w, h, 0, count)
+    img, st = _render(gpu_ctx, w, h, 0, count, recursion=recursion, clock=5, batch=64)
+    assert np.array_equal(img, want, equal_nan=True)
+    assert st["rays"] == wst["rays"]
+
+
 def test_box_scene_without_lights(gpu_ctx, oracle_mod):
     scene = load_scene("box")
     _upload(gpu_ctx, scene, constant_env())
