@@ -48,10 +48,10 @@ struct Box {
 
 struct Item { Box box; float c[3]; int32_t id; };
 
-#ifndef RT_MAX_LEAF
-#define RT_MAX_LEAF 4
-#endif
-constexpr int MAX_LEAF = RT_MAX_LEAF;
+// Largest leaf, by scene size: triangle tests cost about as much as node steps, and the balance moves towards smaller
+// leaves as traversals get longer (measured on MI355X: 424 triangles 3 = 4 > 2, 12 030 triangles 3 > 4, 2, 5;
+// 1 M triangles 2 > 3 > 4).  The leaf code holds up to 7.
+inline int max_leaf_for(uint32_t count) { return count >= 65536u ? 2 : 3; }
 #ifndef RT_BVH_BINS
 #define RT_BVH_BINS 32
 #endif
@@ -63,6 +63,7 @@ constexpr int BINS = RT_BVH_BINS;
 // depth); used when the SAH tree would come out deeper than the traversal stack.
 inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool force_median, HostBvh &out) {
     using namespace bvh_detail;
+    const int MAX_LEAF = max_leaf_for(count);
     std::vector<Item> items(count);
     float max_abs = 0.0f;
     for (uint32_t i = 0; i < count; i++) {
