@@ -107,20 +107,16 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=64)
-    ap.add_argument("--batch-samples", type=int, default=64, help="samples per pass (about 320 bytes of queue memory per pixel-sample of a pass: 42 GB at 1080p)")
+    ap.add_argument("--batch-samples", type=int, default=64, help="samples per pass (about 290 bytes of queue memory per pixel-sample of a pass)")
     ap.add_argument("--pipeline", type=int, default=1)
-    ap.add_argument("--fuse-shade", type=int, default=1)
     ap.add_argument("--accel", type=int, default=-1, help="-1 auto, 0 loops over all triangles, 1 hierarchy")
     ap.add_argument("--workload", choices=("cubes", "obiwan", "c3"), default="cubes")
     ap.add_argument("--grid", type=int, default=724, help="c3: cells per side of the height field")
     ap.add_argument("--atlas", type=int, default=1024, help="c3: edge of the texture layers")
-    ap.add_argument("--refill", type=int, default=-1, help="-1 library default, 0/1 traversal kernels without/with lane refill")
-    ap.add_argument("--pool", type=int, default=-1, help="-1 library default, 0/1 depth 0 without/with the workgroup probe pool")
-    ap.add_argument("--first-in-place", type=int, default=-1, help="-1 library default, 0/1 depth 0 through the queues / in one kernel")
-    ap.add_argument("--inplace-depths", type=int, default=-1, help="-1 library default; bounces after the first with probes in place")
-    ap.add_argument("--share-closest", type=int, default=-1, help="-1 library default; 0/1 closest-hit searches of deeper bounces shared")
-    ap.add_argument("--share", type=int, default=-1, help="-1 library default; 0/1 depth-0 any-hit searches shared among the lanes of a wave")
-    ap.add_argument("--tail", type=int, default=-1, help="-1 library default; 0 no tail kernel, n: once at most 1/n of the batch is left")
+    ap.add_argument("--refill", type=int, default=-1, help="-1 library default, 0/1 closest-hit kernels without/with lane refill")
+    ap.add_argument("--resident", type=int, default=-1, help="-1 library default, 0 never stage a whole hierarchy into LDS")
+    ap.add_argument("--share", type=int, default=-1, help="-1 library default; 0/1 any-hit searches shared among the lanes of a wave")
+    ap.add_argument("--staged-depths", type=int, default=-2, help="-2 library default; bounces after the first that run staged before the tail kernel (-1 all)")
     ap.add_argument("--width", type=int, default=1920, help="target width (the headline metric is quoted at 1920 x 1080)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lane-utilisation", action="store_true",
@@ -154,22 +150,15 @@ def main():
     ctx = g.Context(local_rank)
     ctx.set_option("pipeline", args.pipeline)
     ctx.set_option("batch_samples", args.batch_samples)
-    ctx.set_option("fuse_shade", args.fuse_shade)
     ctx.set_option("accel", args.accel)
     if args.refill >= 0:
         ctx.set_option("refill", args.refill)
-    if args.pool >= 0:
-        ctx.set_option("pool", args.pool)
-    if args.inplace_depths >= 0:
-        ctx.set_option("inplace_depths", args.inplace_depths)
-    if args.share_closest >= 0:
-        ctx.set_option("share_closest", args.share_closest)
+    if args.resident >= 0:
+        ctx.set_option("resident", args.resident)
     if args.share >= 0:
         ctx.set_option("share", args.share)
-    if args.tail >= 0:
-        ctx.set_option("tail", args.tail)
-    if args.first_in_place >= 0:
-        ctx.set_option("first_in_place", args.first_in_place)
+    if args.staged_depths >= -1:
+        ctx.set_option("staged_depths", args.staged_depths)
     ctx.set_option("profiling", 1)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)

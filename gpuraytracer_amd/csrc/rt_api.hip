@@ -38,7 +38,13 @@ struct rt_context {
     bool have_scene = false;
 
     // hierarchies (all triangles; light triangles only), see rt_bvh.h
-    struct DevBvh { float4 *nodes = nullptr, *leaf_geo = nullptr; int *leaf_ids = nullptr; float max_abs = 0.0f; int n_nodes = 0; bool ok = false; };
+    struct DevBvh {
+        float4 *nodes = nullptr, *leaf_geo = nullptr;
+        int *leaf_ids = nullptr;
+        float max_abs = 0.0f;
+        int n_nodes = 0, n_slots = 0, depth = 0;
+        bool ok = false;
+    };
     DevBvh bvh, light_bvh;
     int accel = -1;            // -1 auto (hierarchy from ACCEL_AUTO_MIN triangles on), 0 brute force, 1 hierarchy
 
@@ -51,13 +57,6 @@ struct rt_context {
     DFrame frame;
     bool have_frame = false;
 
-    // per-launch sample tables
-    uint32_t *d_samples = nullptr, *d_light_seeds = nullptr;
-    uint32_t sample_cap = 0;
-    // pinned staging for the two tables, two slots used in turn (see Pipeline::h_coins)
-    uint32_t *h_tables[2] = {nullptr, nullptr};
-    hipEvent_t tables_copied[2] = {nullptr, nullptr};
-    int table_slot = 0;
     uint32_t chain_pos = 0, chain_val = 0;   // light-seed chain: chain_val = hash^chain_pos(clock)
     bool chain_valid = false;
 
@@ -65,14 +64,10 @@ struct rt_context {
     int pipeline = 1;
     int batch_samples = 32;
     int profiling = 0;
-    int fuse_shade = 1;
-    int first_in_place = 1;    // depth 0 in one kernel with the probes in place (k_first); 0: depth 0 through the queues
-    int share_closest = 0;     // deeper bounces: the closest-hit searches are shared as well (closest_hit_shared)
     int share = 1;             // lanes of a wave share the any-hit searches of its probes (anyhit_shared)
-    int inplace_depths = 0;    // bounces after the first that also run their probes in place
-    int tail = 64;             // the tail kernel takes over once at most 1/tail of a batch's paths is left (0: never)
+    int staged_depths = 2;     // bounces after the first that run as staged kernels before the tail kernel takes the rest; -1: all
+    int resident = -1;         // -1 auto (hierarchies that fit are staged into LDS whole), 0 never
     int tonemap = 0;           // rt_read_srgb8: 0 sRGB transfer (displayQuad.fs), 1 ACES film curve first (Scene::exportBMP)
-    int pool = 0;              // 1: depth 0 with the probes of a workgroup pooled (k_first_pool); slower, see there
     int refill = -1;           // -1 auto (lane refill from REFILL_AUTO_MIN triangles on), 0 off, 1 on
 
     // stats
@@ -138,6 +133,7 @@ DBvh device_bvh(const rt_context *ctx, const rt_context::DevBvh &b, bool want) {
     d.max_abs_coord = b.max_abs;
     d.enabled = (want && b.ok) ? 1 : 0;
     d.n_nodes = b.n_nodes;
+    d.n_slots = b.n_slots;
     (void)ctx;
     return d;
 }
@@ -146,6 +142,13 @@ bool use_accel(const rt_context *ctx) {
     if (!ctx->bvh.ok) return false;
     if (ctx->accel < 0) return ctx->count >= ACCEL_AUTO_MIN;
     return ctx->accel != 0;
+}
+
+// Do both hierarchies fit the LDS of a workgroup (KernelCfg::RES)?
+bool fits_lds(const rt_context *ctx) {
+    const rt_context::DevBvh &a = ctx->bvh, &l = ctx->light_bvh;
+    const int records = a.n_nodes + a.n_slots + (l.ok ? l.n_nodes + l.n_slots : 0);
+    return records <= RES_RECORDS && a.depth < RES_STACK && (!l.ok || l.depth < RES_STACK);
 }
 
 void free_bvh(rt_context::DevBvh &b) {
@@ -168,6 +171,8 @@ hipError_t upload_bvh(const rt_triangle_model *tris, uint32_t count, rt_context:
         e = hipMemcpy(out.leaf_ids, hb.leaf_ids.data(), hb.leaf_ids.size() * sizeof(int), hipMemcpyHostToDevice);
     out.max_abs = hb.max_abs_coord;
     out.n_nodes = (int)(hb.nodes.size() / 16);
+    out.n_slots = (int)hb.leaf_ids.size();
+    out.depth = hb.depth;
     out.ok = e == hipSuccess;
     return e;
 }
@@ -246,24 +251,6 @@ __global__ void k_sum_to_rgb(const float4 *__restrict__ sum, unsigned long long 
     rgb[i * 3 + 2] = s.z;
 }
 
-int ensure_sample_tables(rt_context *ctx, uint32_t n) {
-    if (n <= ctx->sample_cap) return RT_OK;
-    if (ctx->d_samples) (void)hipFree(ctx->d_samples);
-    if (ctx->d_light_seeds) (void)hipFree(ctx->d_light_seeds);
-    ctx->d_samples = ctx->d_light_seeds = nullptr;
-    ctx->sample_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_samples, sizeof(uint32_t) * n));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_light_seeds, sizeof(uint32_t) * n));
-    for (int k = 0; k < 2; k++) {
-        if (ctx->h_tables[k]) (void)hipHostFree(ctx->h_tables[k]);      // hipFree above has drained the device
-        ctx->h_tables[k] = nullptr;
-        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_tables[k], sizeof(uint32_t) * 2 * n));
-        if (!ctx->tables_copied[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->tables_copied[k], hipEventDisableTiming));
-    }
-    ctx->sample_cap = n;
-    return RT_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -298,12 +285,6 @@ int rt_destroy(rt_context *ctx) {
     ctx->pipe.release();
     if (ctx->d_env) (void)hipFree(ctx->d_env);
     if (ctx->d_sum_own) (void)hipFree(ctx->d_sum_own);
-    if (ctx->d_samples) (void)hipFree(ctx->d_samples);
-    if (ctx->d_light_seeds) (void)hipFree(ctx->d_light_seeds);
-    for (int k = 0; k < 2; k++) {
-        if (ctx->h_tables[k]) (void)hipHostFree(ctx->h_tables[k]);
-        if (ctx->tables_copied[k]) (void)hipEventDestroy(ctx->tables_copied[k]);
-    }
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -335,7 +316,8 @@ int rt_upload_scene(rt_context *ctx, const rt_triangle_model *models, const rt_t
     if (count == 0 || !models || !shadings || !materials || n_materials == 0)
         return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: empty scene");
     if (lights > count) return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: lights (%u) > count (%u)", lights, count);
-    if (count > 0x3FFFFFFFu) return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: more than 2^30 triangles");
+    // a leaf of the hierarchy is coded as ~((first slot << 3) | count) in 32 bits, and the kernels index records with int
+    if (count >= (1u << 28)) return fail(ctx, RT_ERR_LIMIT, "rt_upload_scene: %u triangles, the limit is 2^28 - 1", count);
     for (uint32_t i = 0; i < count; i++)
         if (shadings[i].material_id >= n_materials)
             return fail(ctx, RT_ERR_INVALID, "rt_upload_scene: triangle %u names material %u of %u", i,
@@ -548,64 +530,68 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
     ctx->frame.height = ctx->height;
     const DScene sc = device_scene(ctx);
 
-    // samples are processed in chunks so that the per-launch tables stay small
-    uint32_t chunk_max = ctx->pipeline == 0 ? 1024u : (uint32_t)(ctx->batch_samples > 0 ? ctx->batch_samples : 1);
+    // samples are processed in passes of at most `batch_samples`; the tables of a pass travel in the kernel arguments
+    uint32_t chunk_max = (uint32_t)(ctx->batch_samples > 0 ? ctx->batch_samples : 1);
+    if (chunk_max > (uint32_t)MAX_BATCH) chunk_max = (uint32_t)MAX_BATCH;
+    if (sample_count < chunk_max) chunk_max = sample_count;
+    const bool acc = use_accel(ctx);
+    PassForm form;
+    form.bvh = acc;
+    form.resident = acc && ctx->resident != 0 && fits_lds(ctx);
+    form.share = acc && ctx->share != 0;
+    form.refill = acc && (ctx->refill < 0 ? ctx->count >= REFILL_AUTO_MIN : ctx->refill != 0);
+    form.staged_depths = ctx->staged_depths;
     if (ctx->pipeline != 0) {
-        // the queues of a pass take about 320 bytes per pixel-sample: fewer samples per pass if that does not fit
-        // (the image does not depend on the batch size)
+        // The queues of a pass are sized for the case that every path survives every bounce; fewer samples per pass if
+        // that does not fit the free device memory (the image does not depend on the pass size).
         const size_t pps = (size_t)(((ctx->width + 7u) >> 3) * ((ctx->height + 7u) >> 3)) * 64u;
-        size_t free_b = 0, total_b = 0;
-        if (pps * chunk_max > ctx->pipe.cap_paths && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t have = ctx->pipe.cap_paths * 320u;       // released before the larger allocation is made
-            while (chunk_max > 1u && (double)pps * chunk_max * 320.0 > 0.9 * (double)(free_b + have)) chunk_max = (chunk_max + 1u) / 2u;
+        const bool h0 = form.refill;
+        if (pps * chunk_max > ctx->pipe.cap_paths || (h0 && !ctx->pipe.have_h0)) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t have = ctx->pipe.queue_bytes();      // released before the larger allocation is made
+                while (chunk_max > 1u && (double)Pipeline::queue_bytes_for(pps * chunk_max, h0) > 0.9 * (double)(free_b + have))
+                    chunk_max = (chunk_max + 1u) / 2u;
+            }
+            const char *msg = nullptr;
+            const hipError_t e = ctx->pipe.ensure(pps * chunk_max, h0, &msg);
+            if (e != hipSuccess)
+                return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s", msg ? msg : "queues",
+                            hipGetErrorString(e));
+        } else if (ctx->pipe.cap_paths / pps < chunk_max) {
+            chunk_max = (uint32_t)(ctx->pipe.cap_paths / pps);
         }
     }
-    int rc = ensure_sample_tables(ctx, chunk_max);
-    if (rc) return rc;
 
     for (uint32_t done = 0; done < sample_count;) {
         const uint32_t n = (sample_count - done < chunk_max) ? sample_count - done : chunk_max;
-        // The uploads are queued behind the previous pass's kernels on the stream, so the device copies cannot be
-        // overwritten early; the pinned slot must not be refilled before its own copy has run.
-        const int slot = ctx->table_slot;
-        ctx->table_slot ^= 1;
-        HIP_TRY(ctx, hipEventSynchronize(ctx->tables_copied[slot]));
-        uint32_t *samples = ctx->h_tables[slot], *seeds = samples + ctx->sample_cap;
-        for (uint32_t k = 0; k < n; k++) {
-            samples[k] = sample_begin + (done + k) * sample_stride;
-            seeds[k] = light_seed_for(ctx, samples[k]);
+        PassTables tab;
+        tab.n = n;
+        for (uint32_t k = 0; k < (uint32_t)MAX_BATCH; k++) {
+            tab.sample[k] = k < n ? sample_begin + (done + k) * sample_stride : 0u;
+            tab.light_seed[k] = k < n ? light_seed_for(ctx, tab.sample[k]) : 0u;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_samples, samples, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_light_seeds, seeds, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->tables_copied[slot], ctx->stream));
-        if (ctx->profiling && ctx->pipeline == 0) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (ctx->pipeline == 0) {
+            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
             const uint32_t tiles = ((ctx->width + 7u) >> 3) * ((ctx->height + 7u) >> 3);
-            hipLaunchKernelGGL(k_trace_mega, dim3(tiles), dim3(64), 0, ctx->stream, sc, ctx->frame, ctx->d_sum,
-                               ctx->d_samples, ctx->d_light_seeds, (int)n, ctx->d_stats);
+            hipLaunchKernelGGL(k_trace_mega, dim3(tiles), dim3(64), 0, ctx->stream, sc, ctx->frame, ctx->d_sum, tab, ctx->d_stats);
             HIP_TRY(ctx, hipGetLastError());
+            if (ctx->profiling) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+                HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+                float ms = 0.0f;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+                ctx->host_stats.trace_ms += (double)ms;
+                ctx->host_stats.extend_ms += (double)ms;     // the single kernel holds every stage
+                ctx->host_stats.extend_launches++;
+            }
         } else {
             const char *msg = nullptr;
-            ctx->pipe.h_light_seeds.assign(seeds, seeds + n);
-            const bool acc = use_accel(ctx);
-            hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame,
-                                         ctx->d_sum, ctx->d_samples, (int)n, ctx->stream, ctx->profiling != 0,
-                                         ctx->fuse_shade != 0,
-                                         ctx->refill < 0 ? ctx->count >= REFILL_AUTO_MIN : ctx->refill != 0,
-                                         ctx->pool != 0, ctx->first_in_place != 0, ctx->tail, ctx->inplace_depths, ctx->share != 0, ctx->share_closest != 0,
-                                         &ctx->host_stats, &msg);
+            const hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame,
+                                               ctx->d_sum, tab, ctx->stream, ctx->profiling != 0, form, &ctx->host_stats, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
                             msg ? msg : "pipeline", hipGetErrorString(e));
-        }
-        if (ctx->profiling && ctx->pipeline == 0) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-            HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-            float ms = 0.0f;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            ctx->host_stats.trace_ms += (double)ms;
-            ctx->host_stats.extend_ms += (double)ms;     // the single kernel holds every stage
-            ctx->host_stats.extend_launches++;
         }
         done += n;
     }
@@ -706,11 +692,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     if (!ctx || !out) return RT_ERR_INVALID;
     if (bind_device(ctx)) return RT_ERR_DEVICE;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    {
-        const double before = ctx->host_stats.extend_ms + ctx->host_stats.probe_ms + ctx->host_stats.shade_ms;
-        HIP_TRY(ctx, ctx->pipe.collect_times(&ctx->host_stats));
-        ctx->host_stats.trace_ms += ctx->host_stats.extend_ms + ctx->host_stats.probe_ms + ctx->host_stats.shade_ms - before;
-    }
+    HIP_TRY(ctx, ctx->pipe.collect_times(&ctx->host_stats));
     DStats ds;
     HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
     unsigned long long ws[WSTAT_SLOTS];
@@ -735,6 +717,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     s.bvh_probe_nodes = ds.probe_nodes;
     s.bvh_probe_tris = ds.probe_tris;
     s.depth1_paths = ws[WSTAT_DEPTH1];
+    s.queue_bytes = ctx->pipe.queue_bytes();
     *out = s;
     return RT_OK;
 }
@@ -747,8 +730,9 @@ int rt_reset_stats(rt_context *ctx) {
     HIP_TRY(ctx, ctx->pipe.reset_wstats(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
-    rt_stats scratch;
-    HIP_TRY(ctx, ctx->pipe.collect_times(&scratch));
+    rt_stats discarded;
+    memset(&discarded, 0, sizeof(discarded));
+    HIP_TRY(ctx, ctx->pipe.collect_times(&discarded));
     return RT_OK;
 }
 
@@ -758,32 +742,23 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
         if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "pipeline must be 0 or 1");
         ctx->pipeline = (int)value;
     } else if (!strcmp(name, "batch_samples")) {
-        if (value < 1 || value > 256) return fail(ctx, RT_ERR_LIMIT, "batch_samples must be in [1, 256]");
+        if (value < 1 || value > MAX_BATCH) return fail(ctx, RT_ERR_LIMIT, "batch_samples must be in [1, %d]", MAX_BATCH);
         ctx->batch_samples = (int)value;
     } else if (!strcmp(name, "accel")) {
         if (value < -1 || value > 1) return fail(ctx, RT_ERR_INVALID, "accel must be -1 (auto), 0 or 1");
         ctx->accel = (int)value;
-    } else if (!strcmp(name, "fuse_shade")) {
-        ctx->fuse_shade = value ? 1 : 0;
     } else if (!strcmp(name, "refill")) {
         ctx->refill = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (!strcmp(name, "resident")) {
+        ctx->resident = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(name, "tonemap")) {
         if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "tonemap must be 0 or 1");
         ctx->tonemap = (int)value;
-    } else if (!strcmp(name, "share_closest")) {
-        ctx->share_closest = value ? 1 : 0;
     } else if (!strcmp(name, "share")) {
         ctx->share = value ? 1 : 0;
-    } else if (!strcmp(name, "inplace_depths")) {
-        if (value < 0 || value > 4096) return fail(ctx, RT_ERR_INVALID, "inplace_depths must be in [0, 4096]");
-        ctx->inplace_depths = (int)value;
-    } else if (!strcmp(name, "tail")) {
-        if (value < 0 || value > 65536) return fail(ctx, RT_ERR_INVALID, "tail must be in [0, 65536]");
-        ctx->tail = (int)value;
-    } else if (!strcmp(name, "first_in_place")) {
-        ctx->first_in_place = value ? 1 : 0;
-    } else if (!strcmp(name, "pool")) {
-        ctx->pool = value ? 1 : 0;
+    } else if (!strcmp(name, "staged_depths")) {
+        if (value < -1 || value > 4096) return fail(ctx, RT_ERR_INVALID, "staged_depths must be in [-1, 4096]");
+        ctx->staged_depths = (int)value;
     } else if (!strcmp(name, "profiling")) {
         ctx->profiling = value ? 1 : 0;
     } else {

@@ -42,6 +42,7 @@ struct DBvh {
     float max_abs_coord;
     int enabled;
     int n_nodes;
+    int n_slots;             // leaf slots (= triangles)
 };
 
 #ifndef RT_BVH_STACK
@@ -56,12 +57,22 @@ constexpr int BVH_LIGHT_TOP_NODES = 64;              // the same for the hierarc
 // workgroup's copy of the first n_top nodes of the hierarchy (breadth-first order, so these are the levels
 // nearest the root).  Fetching those from LDS takes the most frequent node reads off the vector memory
 // path, which is the busiest unit of the traversal kernels.
+//
+// RES ("resident"): the whole hierarchy lives in LDS, leaf triangle records included.  A scene of a few hundred
+// triangles (all the reference's bundled scenes but one) fits next to the stacks, and then no step of a traversal
+// touches the vector memory path: a leaf test waits for an LDS read (about 100 clocks) instead of an L1/L2 hit
+// (several hundred), which matters because the traversal kernels are bound by the latency of their dependent
+// accesses as much as by instruction issue (measured: 2 / 3 / 4 waves per SIMD take 18.3 / 14.2 / 12.6 ms).
 typedef const __attribute__((address_space(3))) v4f *lds_v4f_ptr;
-struct BvhScratch {
+template <bool RES_>
+struct BvhScratchT {
+    static constexpr bool RES = RES_;
     int *stack;
     lds_v4f_ptr top;      // LDS address space: the reads become ds_read_b128, not generic-address loads
     int n_top;
+    lds_v4f_ptr leaves;   // RES: the leaf records (4 x float4 per slot)
 };
+typedef BvhScratchT<false> BvhScratch;
 
 // Cooperative copy of the top of the hierarchy into LDS; every thread of the workgroup calls it.
 RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top, int max_nodes = BVH_TOP_NODES) {
@@ -69,6 +80,12 @@ RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top, int max_nodes = BVH_TOP_NODES
     for (int i = threadIdx.x; i < n_top * 4; i += blockDim.x) top[i] = ((const v4f *)bv.nodes)[i];
     __syncthreads();
     return n_top;
+}
+// The same for the leaf records of a resident hierarchy.
+RT_DEV void bvh_stage_leaves(const DBvh &bv, v4f *leaves) {
+    const int n = bv.enabled ? bv.n_slots * 4 : 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) leaves[i] = ((const v4f *)bv.leaf_geo)[i];
+    __syncthreads();
 }
 
 struct BvhRay {
@@ -134,8 +151,8 @@ struct TravState {
 // "while-while" order: all lanes first descend through inner nodes until each holds a leaf (or has finished),
 // then all leaves are processed together; this keeps box tests and triangle tests of a wave from
 // interleaving lane by lane.
-template <bool BUDGETED = false, typename LeafFn, typename LimitFn>
-RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const BvhScratch &ws, TravState &ts, int stop_at, LeafFn leaf,
+template <bool BUDGETED = false, class WS, typename LeafFn, typename LimitFn>
+RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravState &ts, int stop_at, LeafFn leaf,
                         LimitFn t_limit, BvhCounters &cnt, bool at_least_one = false, int node_budget = 1 << 30) {
     int *stack = ws.stack;
     int sp = ts.sp;
@@ -148,7 +165,7 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const BvhScratch &ws, 
         int budget = node_budget;
         while (run && node >= 0 && (!BUDGETED || budget-- > 0)) {
             v4f q0, q1, q2, q3;
-            if (node < ws.n_top) {
+            if (WS::RES || node < ws.n_top) {
                 q0 = ws.top[4 * node + 0]; q1 = ws.top[4 * node + 1]; q2 = ws.top[4 * node + 2]; q3 = ws.top[4 * node + 3];
             } else {
                 const v4f *g = (const v4f *)bv.nodes;
@@ -201,8 +218,8 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const BvhScratch &ws, 
 }
 
 // One traversal from the root to the end for the lanes with `active`.
-template <typename LeafFn, typename LimitFn>
-RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const BvhScratch &ws, LeafFn leaf, LimitFn t_limit,
+template <class WS, typename LeafFn, typename LimitFn>
+RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const WS &ws, LeafFn leaf, LimitFn t_limit,
                          BvhCounters &cnt) {
     TravState ts;
     ts.node = 0; ts.sp = 0; ts.run = active;
@@ -212,9 +229,20 @@ RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const Bv
 // The triangle record of a leaf slot (3 of the 4 float4 of the slot).  Its index is the first word of the
 // fourth float4; callers fetch it with leaf_tri_id only for triangles that passed their test, so the common
 // case costs three vector loads instead of four.
-RT_DEV int leaf_tri_id(const DBvh &bv, int slot) { return __float_as_int(bv.leaf_geo[4 * slot + 3].x); }
-RT_DEV Tri load_leaf_tri(const DBvh &bv, int slot) {
-    const float4 a = bv.leaf_geo[4 * slot + 0], b = bv.leaf_geo[4 * slot + 1], c = bv.leaf_geo[4 * slot + 2];
+template <class WS>
+RT_DEV int leaf_tri_id(const DBvh &bv, const WS &ws, int slot) {
+    if (WS::RES) return __float_as_int(ws.leaves[4 * slot + 3].x);
+    return __float_as_int(bv.leaf_geo[4 * slot + 3].x);
+}
+template <class WS>
+RT_DEV Tri load_leaf_tri(const DBvh &bv, const WS &ws, int slot) {
+    v4f a, b, c;
+    if (WS::RES) {
+        a = ws.leaves[4 * slot + 0]; b = ws.leaves[4 * slot + 1]; c = ws.leaves[4 * slot + 2];
+    } else {
+        const v4f *g = (const v4f *)bv.leaf_geo;
+        a = g[4 * slot + 0]; b = g[4 * slot + 1]; c = g[4 * slot + 2];
+    }
     Tri t;
     t.n = mk3(a.x, a.y, a.z);
     t.p = mk3(a.w, b.x, b.y);
@@ -238,8 +266,10 @@ RT_DEV void closest_fold_reset(ClosestFold &cf, float w_init) {
 }
 // Tests the triangle of leaf slot `slot` and folds it in if it is a candidate.  Triangles outside
 // [begin_id, end_id) and `current` are skipped.
-RT_DEV void closest_fold_leaf(const DBvh &bv, const Ray &ray, int slot, int begin_id, int end_id, int current, ClosestFold &cf) {
-    const Tri t = load_leaf_tri(bv, slot);
+template <class WS>
+RT_DEV void closest_fold_leaf(const DBvh &bv, const WS &ws, const Ray &ray, int slot, int begin_id, int end_id, int current,
+                              ClosestFold &cf) {
+    const Tri t = load_leaf_tri(bv, ws, slot);
     const float det = -dot(ray.d, t.n);
     const f3 delta = ray.o - t.p;
     const float rd = dot(t.n, delta);
@@ -248,7 +278,7 @@ RT_DEV void closest_fold_leaf(const DBvh &bv, const Ray &ray, int slot, int begi
     pt.det = det; pt.rd = rd; pt.delta = delta;
     float rx, ry;
     if (!inside_test(ray, t, pt, rx, ry)) return;
-    const int id = leaf_tri_id(bv, slot);
+    const int id = leaf_tri_id(bv, ws, slot);
     if (id < begin_id || id >= end_id || id == current) return;
     // a candidate: rule 3 between it and the running best
     bool take;
@@ -277,12 +307,13 @@ RT_DEV void closest_fold_redo(const DScene &sc, const Ray &ray, bool redo, int b
 // restricts the triangles considered (the glossy probe folds over the light triangles only),
 // `current` is skipped.  Returns the triangle id or -1; isec = (x, y, rd, det) of the winner, or
 // (0, 0, -1, w_init) when nothing was hit.
+template <class WS>
 RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, int begin_id, int end_id,
-                           int current, float w_init, const BvhScratch &ws, f4 &isec, BvhCounters &cnt) {
+                           int current, float w_init, const WS &ws, f4 &isec, BvhCounters &cnt) {
     const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
     ClosestFold cf;
     closest_fold_reset(cf, w_init);
-    auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ray, slot, begin_id, end_id, current, cf); return true; };
+    auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, begin_id, end_id, current, cf); return true; };
     auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
     bvh_traverse(bv, br, active && br.finite, ws, leaf, limit, cnt);
     closest_fold_redo(sc, ray, active && (!br.finite || cf.n_near > 2), begin_id, end_id, current, w_init, cf);
@@ -308,8 +339,8 @@ typedef volatile __attribute__((address_space(3))) unsigned char *lds_u8_ptr;
 
 RT_DEV float lane_read(float v, int lane4) { return __int_as_float(__builtin_amdgcn_ds_bpermute(lane4, __float_as_int(v))); }
 
-template <int NODE_BUDGET, typename TestFn>
-RT_DEV bool anyhit_shared(const DBvh &bv, const BvhScratch &ws, lds_u8_ptr scratch, Ray ray, float lim, f3 extra, bool active,
+template <int NODE_BUDGET, class WS, typename TestFn>
+RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray ray, float lim, f3 extra, bool active,
                           TestFn test, BvhCounters &cnt) {
     const int lane = (int)(threadIdx.x & 63u);
     lds_u8_ptr flags = scratch, table = scratch + 64;
@@ -363,119 +394,17 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const BvhScratch &ws, lds_u8_ptr scrat
     return flags[lane] != 0;
 }
 
-// Closest-hit search in which the lanes of a wave share the work.  The closest hit is the fold of rule 3 over the
-// candidates of all subtrees, and that fold does not depend on the order for up to two candidates near the closest
-// depth (more make the lane redo the index-order loop, as in closest_hit_bvh).  So, as in anyhit_shared, a lane
-// without work takes the newest stack entry of a busy lane together with its ray, folds the candidates of that
-// subtree, and hands the partial fold back: it puts its lane number into the owner's one-byte mailbox in LDS, and
-// the owner pulls the fold through ds_bpermute and merges it into its own.  Partial folds prune with the depth
-// known when the subtree changed hands, which is looser than the sequential search's, never tighter.
-// Merging near-candidate counts adds the counts of the partial folds whose depth lies within the margin of the
-// merged one; that can over-count (more redos), never under-count.
-RT_DEV void closest_fold_merge(ClosestFold &r, const ClosestFold &w) {
-    if (w.best < 0) return;
-    bool take;
-    if (r.best < 0) take = true;
-    else if (w.best > r.best) take = !(w.st.z * r.st.w > r.st.z * w.st.w);
-    else take = (r.st.z * w.st.w > w.st.z * r.st.w);
-    const float g = __builtin_fminf(r.t_min, w.t_min);
-    const int n = ((r.t_min <= g * BVH_NEAR) ? r.n_near : 0) + ((w.t_min <= g * BVH_NEAR) ? w.n_near : 0);
-    r.t_min = g;
-    r.n_near = n;
-    if (take) { r.best = w.best; r.st = w.st; }
-}
-
-template <int NODE_BUDGET>
-RT_DEV int closest_hit_shared(const DScene &sc, const DBvh &bv, const Ray &ray_in, bool active, int begin_id, int end_id,
-                              int current_in, float w_init, const BvhScratch &ws, lds_u8_ptr scratch, f4 &isec,
-                              BvhCounters &cnt) {
-    const int lane = (int)(threadIdx.x & 63u);
-    lds_u8_ptr mail = scratch, table = scratch + 64;
-    Ray ray = ray_in;
-    int current = current_in, owner = lane;
-    BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
-    const bool own_finite = br.finite;
-    ClosestFold res, job;            // res: the fold of this lane's own query; job: of the subtree being searched now
-    closest_fold_reset(res, w_init);
-    closest_fold_reset(job, w_init);
-    float bound = __builtin_inff();  // depth beyond which nothing can matter to the job's owner
-    bool busy = active && br.finite;
-    TravState ts;
-    ts.node = 0; ts.sp = 0; ts.run = busy;
-    auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ray, slot, begin_id, end_id, current, job); return true; };
-    auto limit = [&]() -> float { return __builtin_fminf(job.t_min, bound) * BVH_NEAR; };
-    for (;;) {
-        // jobs that have ended: an own one is merged here, a helper's fold goes to its owner
-        const bool ended = busy && !ts.run;
-        if (ended && owner == lane) { closest_fold_merge(res, job); busy = false; }
-        bool want = ended && owner != lane;
-        if (want && job.best < 0) { want = false; busy = false; }
-        while (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-            mail[lane] = 0xFF;
-            if (want) mail[owner] = (unsigned char)lane;           // one sender per owner and turn: the last writer
-            const int sender = (int)mail[lane];
-            const bool has = sender != 0xFF;
-            const int from4 = 4 * (has ? sender : lane);
-            ClosestFold in;
-            in.best = __builtin_amdgcn_ds_bpermute(from4, job.best);
-            in.n_near = __builtin_amdgcn_ds_bpermute(from4, job.n_near);
-            in.t_min = lane_read(job.t_min, from4);
-            in.st.x = lane_read(job.st.x, from4); in.st.y = lane_read(job.st.y, from4);
-            in.st.z = lane_read(job.st.z, from4); in.st.w = lane_read(job.st.w, from4);
-            if (has) closest_fold_merge(res, in);
-            if (want && (int)mail[owner] == lane) { want = false; busy = false; }
-        }
-        if (busy && owner == lane) bound = res.t_min;               // what helpers have found prunes the own search
-        const unsigned long long running = __builtin_amdgcn_ballot_w64(ts.run);
-        if (running == 0ull) break;
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
-        const unsigned long long donors = __builtin_amdgcn_ballot_w64(ts.run && ts.sp > 0);
-        const int n_idle = (int)__popcll(idle), n_donors = (int)__popcll(donors);
-        if (n_idle >= SHARE_MIN_IDLE && n_donors > 0) {
-            const int n_take = n_idle < n_donors ? n_idle : n_donors;
-            const int d_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
-            const int i_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const bool gives = ts.run && ts.sp > 0 && d_rank < n_take;
-            const bool takes = !busy && i_rank < n_take;
-            if (gives) table[d_rank] = (unsigned char)lane;
-            int given = 0;
-            if (gives) { ts.sp--; given = ws.stack[64 * ts.sp]; }
-            const int from4 = takes ? 4 * (int)table[i_rank] : 4 * lane;
-            const int t_node = __builtin_amdgcn_ds_bpermute(from4, given);
-            const int t_owner = __builtin_amdgcn_ds_bpermute(from4, owner);
-            const int t_current = __builtin_amdgcn_ds_bpermute(from4, current);
-            const float t_bound = lane_read(__builtin_fminf(job.t_min, bound), from4);
-            Ray r2; BvhRay b2;
-            r2.o = mk3(lane_read(ray.o.x, from4), lane_read(ray.o.y, from4), lane_read(ray.o.z, from4));
-            r2.d = mk3(lane_read(ray.d.x, from4), lane_read(ray.d.y, from4), lane_read(ray.d.z, from4));
-            b2.inv = mk3(lane_read(br.inv.x, from4), lane_read(br.inv.y, from4), lane_read(br.inv.z, from4));
-            b2.oi_lo = mk3(lane_read(br.oi_lo.x, from4), lane_read(br.oi_lo.y, from4), lane_read(br.oi_lo.z, from4));
-            b2.oi_hi = mk3(lane_read(br.oi_hi.x, from4), lane_read(br.oi_hi.y, from4), lane_read(br.oi_hi.z, from4));
-            if (takes) {
-                ray = r2; br.inv = b2.inv; br.oi_lo = b2.oi_lo; br.oi_hi = b2.oi_hi;
-                owner = t_owner; current = t_current; bound = t_bound;
-                closest_fold_reset(job, w_init);
-                ts.node = t_node; ts.sp = 0; ts.run = true;
-                busy = true;
-            }
-        }
-        bvh_advance<(NODE_BUDGET > 0)>(bv, br, ws, ts, SHARE_MIN_IDLE, leaf, limit, cnt, true, NODE_BUDGET > 0 ? NODE_BUDGET : 1 << 30);
-    }
-    closest_fold_redo(sc, ray_in, active && (!own_finite || res.n_near > 2), begin_id, end_id, current_in, w_init, res);
-    isec = res.st;
-    return res.best;
-}
-
 // sampleLight's occlusion query (raytracer.glsl:372-378): is any triangle != current hit by
 // intersectTriangleShadow within max_t?
+template <class WS>
 RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
-                               const BvhScratch &ws, BvhCounters &cnt) {
+                               const WS &ws, BvhCounters &cnt) {
     const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
     const bool ok = br.finite && ((max_t - max_t) == 0.0f);
     bool blocked = false;
     auto leaf = [&](int slot) -> bool {
-        const Tri t = load_leaf_tri(bv, slot);
-        if (intersect_triangle_shadow(ray, t, max_t) && leaf_tri_id(bv, slot) != current) { blocked = true; return false; }
+        const Tri t = load_leaf_tri(bv, ws, slot);
+        if (intersect_triangle_shadow(ray, t, max_t) && leaf_tri_id(bv, ws, slot) != current) { blocked = true; return false; }
         return true;
     };
     const float lim = max_t * BVH_NEAR;
@@ -491,8 +420,9 @@ RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
 
 // Second phase of sampleLightGlossy (raytracer.glsl:406-419): does any triangle of [lights, count)
 // other than `current` pass intersectTriangle against the fixed state `isec`?
+template <class WS>
 RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, const f4 &isec, int current, bool active,
-                               const BvhScratch &ws, BvhCounters &cnt) {
+                               const WS &ws, BvhCounters &cnt) {
     const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
     const bool bounded = isec.z >= 0.0f;                 // a light was hit: only triangles not farther than it matter
     const float t_light = isec.z / isec.w;
@@ -500,11 +430,11 @@ RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
     bool blocked = false;
     const int lights = sc.lights;
     auto leaf = [&](int slot) -> bool {
-        const Tri t = load_leaf_tri(bv, slot);
+        const Tri t = load_leaf_tri(bv, ws, slot);
         PlaneTest pt;
         float rx, ry;
         if (plane_test_closest(ray, t, isec, pt) && inside_test(ray, t, pt, rx, ry)) {
-            const int id = leaf_tri_id(bv, slot);
+            const int id = leaf_tri_id(bv, ws, slot);
             if (id >= lights && id != current) { blocked = true; return false; }
         }
         return true;
@@ -522,8 +452,9 @@ RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
 
 // sampleLightGlossy's search (raytracer.glsl:403-419) in its two-phase form, see glossy_search_bf.
 // `lbv` is a hierarchy over the light triangles [0, lights) alone; `ws` holds the LDS copy of `bv`, `lws` that of `lbv`.
+template <class WS>
 RT_DEV int glossy_search_bvh(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &ray, int current, bool active,
-                             int &light_id, f4 &isec, const BvhScratch &ws, const BvhScratch &lws, BvhCounters &cnt) {
+                             int &light_id, f4 &isec, const WS &ws, const WS &lws, BvhCounters &cnt) {
     const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
     if (lbv.enabled) {
         light_id = closest_hit_bvh(sc, lbv, ray, active, 0, lights, current, 0.0f, lws, isec, cnt);
@@ -537,14 +468,14 @@ RT_DEV int glossy_search_bvh(const DScene &sc, const DBvh &bv, const DBvh &lbv, 
 }
 
 // shadow_any_hit_bvh and glossy_search_bvh with the any-hit part shared among the lanes of the wave (anyhit_shared).
-template <int NODE_BUDGET>
+template <int NODE_BUDGET, class WS>
 RT_DEV bool shadow_any_hit_shared(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
-                                  const BvhScratch &ws, lds_u8_ptr scratch, BvhCounters &cnt) {
+                                  const WS &ws, lds_u8_ptr scratch, BvhCounters &cnt) {
     const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
     const bool ok = ((s - s) == 0.0f) && ((max_t - max_t) == 0.0f);
     auto test = [&](const Ray &r, const f3 &e, int slot) -> bool {
-        const Tri t = load_leaf_tri(bv, slot);
-        return intersect_triangle_shadow(r, t, e.x) && leaf_tri_id(bv, slot) != __float_as_int(e.z);
+        const Tri t = load_leaf_tri(bv, ws, slot);
+        return intersect_triangle_shadow(r, t, e.x) && leaf_tri_id(bv, ws, slot) != __float_as_int(e.z);
     };
     bool blocked = anyhit_shared<NODE_BUDGET>(bv, ws, scratch, ray, max_t * BVH_NEAR, mk3(max_t, 0.0f, __int_as_float(current)), active && ok,
                                  test, cnt);
@@ -556,9 +487,9 @@ RT_DEV bool shadow_any_hit_shared(const DScene &sc, const DBvh &bv, const Ray &r
     return blocked;
 }
 
-template <int NODE_BUDGET>
+template <int NODE_BUDGET, class WS>
 RT_DEV int glossy_search_shared(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &ray, int current, bool active,
-                                int &light_id, f4 &isec, const BvhScratch &ws, const BvhScratch &lws, lds_u8_ptr scratch,
+                                int &light_id, f4 &isec, const WS &ws, const WS &lws, lds_u8_ptr scratch,
                                 BvhCounters &cnt) {
     const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
     if (lbv.enabled) {
@@ -574,13 +505,13 @@ RT_DEV int glossy_search_shared(const DScene &sc, const DBvh &bv, const DBvh &lb
         const float t_light = isec.z / isec.w;
         const bool ok = ((s - s) == 0.0f) && (!bounded || (t_light - t_light) == 0.0f);
         auto test = [&](const Ray &r, const f3 &e, int slot) -> bool {
-            const Tri t = load_leaf_tri(bv, slot);
+            const Tri t = load_leaf_tri(bv, ws, slot);
             f4 st;
             st.x = 0.0f; st.y = 0.0f; st.z = e.x; st.w = e.y;
             PlaneTest pt;
             float rx, ry;
             if (!(plane_test_closest(r, t, st, pt) && inside_test(r, t, pt, rx, ry))) return false;
-            const int id = leaf_tri_id(bv, slot);
+            const int id = leaf_tri_id(bv, ws, slot);
             return id >= lights && id != __float_as_int(e.z);
         };
         blocked = anyhit_shared<NODE_BUDGET>(bv, ws, scratch, ray, bounded ? t_light * BVH_NEAR : __builtin_inff(),
@@ -606,6 +537,7 @@ __global__ __launch_bounds__(64) void k_closest_hit_batch_bvh(DScene sc, DBvh bv
     BvhScratch ws;
     ws.stack = stack_mem + threadIdx.x;
     ws.top = (lds_v4f_ptr)top_mem;
+    ws.leaves = nullptr;
     ws.n_top = bv.enabled ? (bv.n_nodes < 64 ? bv.n_nodes : 64) : 0;
     for (int i = threadIdx.x; i < ws.n_top * 4; i += 64) top_mem[i] = ((const v4f *)bv.nodes)[i];
     __syncthreads();

@@ -16,6 +16,24 @@ struct DStats {
     unsigned long long ext_nodes, ext_tris, probe_nodes, probe_tris;
 };
 
+// The per-pass tables travel by value in the kernel arguments (1 KB), so a pass needs no host-to-device copy and no
+// staging buffer: SAMPLE of every slot of the batch, and its light_seed = CLOCK hashed SAMPLE times
+// (raytracer.glsl:595-598).  The coin of a bounce (raytracer.glsl:553: unitFloat(light_seed) < 0.5, drawn once per
+// bounce from a stream all pixels of a sample share) is recomputed from light_seed where it is needed.
+constexpr int MAX_BATCH = 128;
+struct PassTables {
+    uint32_t n;
+    uint32_t sample[MAX_BATCH];
+    uint32_t light_seed[MAX_BATCH];
+};
+// light_seed after the draws of `depth` earlier bounces
+RT_DEV uint32_t light_seed_at(uint32_t light_seed, int depth) {
+    for (int d = 0; d < depth; d++) light_seed = pcg_hash(light_seed);
+    return light_seed;
+}
+// Draws the bounce's coin: true = sampleLight, false = sampleLightGlossy.
+RT_DEV bool draw_coin(uint32_t &light_seed) { return unit_float(light_seed) < 0.5f; }
+
 RT_DEV unsigned long long wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -116,9 +134,7 @@ RT_DEV int glossy_search_bf(const DScene &sc, const Ray &ray, int current, bool 
 // One wave per 8x8 pixel tile (the reference's workgroup shape, raytracer.glsl:3), one lane per
 // pixel; a lane walks its whole path.  Simple and exact, but lanes whose path has ended idle until
 // the longest path of the wave is done; the staged pipeline below removes that.
-__global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 *__restrict__ sum,
-                                                   const uint32_t *__restrict__ samples,
-                                                   const uint32_t *__restrict__ light_seeds, int n_samples,
+__global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 *__restrict__ sum, PassTables tab,
                                                    DStats *__restrict__ stats) {
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
     const uint32_t tile = blockIdx.x;
@@ -136,9 +152,9 @@ __global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 
     }
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
 
-    for (int k = 0; k < n_samples; k++) {
-        const uint32_t sample = samples[k];
-        uint32_t light_seed = light_seeds[k];
+    for (uint32_t k = 0; k < tab.n; k++) {
+        const uint32_t sample = tab.sample[k];
+        uint32_t light_seed = tab.light_seed[k];
         PathState ps;
         ps.seed = pixel_seed(fr, tx, ty, sample);
         const Ray cam = camera_ray(fr, tx, ty, ps.seed);
@@ -151,7 +167,7 @@ __global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 
 
         for (int depth = 0; depth < max_depth; depth++) {
             if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
-            const bool coin_diffuse = unit_float(light_seed) < 0.5f;       // :553, same for every pixel
+            const bool coin_diffuse = draw_coin(light_seed);               // :553, same for every pixel
             Ray ray; ray.o = ps.o; ray.d = ps.d;
             f4 isec;
             const int hit = closest_hit_bf(sc, ray, isec);

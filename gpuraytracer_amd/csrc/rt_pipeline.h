@@ -13,7 +13,12 @@
 //            are finished (roulette) and go to the next extend queue
 //   shadow   occlusion loop of sampleLight + rest of the bounce        -> next extend queue
 //   glossy   search loop of sampleLightGlossy + rest of the bounce     -> next extend queue
+//   tail     after a few staged bounces: every lane walks the rest of a path, taking the next record of its
+//            wave's queue region when its path ends
 //   resolve  adds the radiance of the batch's paths to the per-pixel sums in ascending sample order
+//
+// The launch sequence of a pass is fixed (no decision needs a value read back from the device: a stage whose
+// queue region is empty ends at once), so rt_trace only enqueues work and can be captured in a HIP graph.
 //
 // A queue entry is the path's whole state (a record), not an index into a state array: the survivors of a
 // bounce are a sparse subset of the paths, and gathering 16-byte fields of every fifth path from planes
@@ -26,15 +31,16 @@
 //   path record   xa = (o.xyz, d.x)  xb = (d.yz, path.xy)  xc = (path.z, energy.xyz)
 //                 xd = (seed, path id, kept flags, -)
 //   probe record  pa, pb, pc as above (state after the bounce's direction change)
-//                 pd = (seed, path id, current triangle | kept flags << 30, closest light of glossy pass 1)
+//                 pd = (seed, path id, current triangle | kept flags << 30, -)
 //                 p0 = (probe_d.xyz, max_t)
 //                 p1 = (lit.xyz, roughness), p2 = (albedo.xyz, -) for shadow probes
-//                 p1 = (specular.xyz, w), p2 = (x, y, rd, det) of the closest light for glossy probes
+//                 p1 = (specular.xyz, w) for glossy probes
 //   Shadow records fill a region of the probe queue from its front, glossy records from its back.
 // By path id:     energy = radiance of a path that has ended (written once, read by resolve)
-//                 kd, ks = kept light results (see struct PathState), touched only when their flag is set
-//                 h0     = (u, v, t, hit triangle id) of the unfused form at depth 0; at depth >= 1 h0 is
-//                          indexed like the extend queue being read
+//                 kd, ks = kept light results (see struct PathState) of paths that go on, touched only when their
+//                          flag is set
+//                 h0     = (u, v, t, hit triangle id) beside each record of the extend queue being read (only
+//                          the lane-refill form of the extend stage uses it)
 // Path id = slot * paths_per_sample + tile * 64 + lane, where `slot` is the sample's position in
 // the batch and (tile, lane) is the 8x8 pixel tile and the pixel inside it, so that the depth-0
 // wave holds the same 64 pixels as a reference workgroup.
@@ -65,6 +71,96 @@ RT_DEV uint32_t wave_index() {
 }
 RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
 
+// Compile-time form of a traversal kernel.
+//   BVH    hierarchy traversal (false: the reference's loops over all triangles)
+//   SHARE  any-hit searches shared among the lanes of a wave: 0 off, 1 on, 2 on with a node-step budget per round
+//   RES    the whole hierarchy, leaf triangles included, is staged into LDS (scenes of a few hundred triangles)
+#ifndef RT_RES_STACK
+#define RT_RES_STACK 16
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4                               // waves per SIMD the traversal kernels are compiled for (register budget)
+#endif
+constexpr int RES_STACK = RT_RES_STACK;              // traversal stack entries of the resident form (hierarchy depth < RES_STACK)
+constexpr int RES_RECORDS = 736;                     // 64-byte records (nodes + leaf slots of both hierarchies) that fit: 46 KB
+template <bool BVH_, int SHARE_, bool RES_>
+struct KernelCfg {
+    static constexpr bool BVH = BVH_;
+    static constexpr int SHARE = SHARE_;
+    static constexpr bool RES = RES_;
+    static constexpr int STACK = RES_ ? RES_STACK : BVH_STACK;
+    static constexpr int NODE_BUDGET = SHARE_ == 2 ? SHARE_NODE_BUDGET : 0;
+    typedef BvhScratchT<RES_> WS;
+    // LDS of a workgroup: the stacks; then either the cached tops of the two hierarchies (192 + 64 nodes; with SHARE the
+    // last 16 node slots of the second are the waves' 128-byte exchange areas) or the resident scene and 1 KB of
+    // exchange areas.  80 KB at most: two workgroups per CU.
+    static constexpr int STACK_INTS = BVH_ ? STACK * 64 * WG_WAVES : 64;
+    static constexpr int SCENE_V4F = !BVH_ ? 1 : (RES_ ? RES_RECORDS * 4 : (BVH_TOP_NODES + BVH_LIGHT_TOP_NODES) * 4);
+    static constexpr int SHARE_BYTES = (BVH_ && RES_) ? 128 * WG_WAVES : 1;
+};
+
+// Fills the LDS of a traversal kernel and the scratch descriptors of the two hierarchies; every thread of the
+// workgroup calls it.  `with_light`: the kernel searches the hierarchy over the emissive triangles as well.
+template <class CFG>
+RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, int *stack_mem, v4f *scene_mem,
+                              unsigned char *share_mem, typename CFG::WS &ws, typename CFG::WS &lws, lds_u8_ptr &share) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    ws.stack = stack_mem + (CFG::BVH ? wv * (CFG::STACK * 64) + lane : 0);
+    ws.top = (lds_v4f_ptr)scene_mem;
+    ws.leaves = nullptr;
+    ws.n_top = 0;
+    lws = ws;
+    share = (lds_u8_ptr)share_mem;
+    if (!CFG::BVH) return;
+    if (CFG::RES) {
+        v4f *nodes = scene_mem, *leaves = nodes + 4 * bv.n_nodes;
+        v4f *lnodes = leaves + 4 * bv.n_slots, *lleaves = lnodes + 4 * lbv.n_nodes;
+        ws.n_top = bvh_stage_top(bv, nodes, bv.n_nodes);
+        ws.leaves = (lds_v4f_ptr)leaves;
+        bvh_stage_leaves(bv, leaves);
+        lws.top = (lds_v4f_ptr)lnodes;
+        lws.leaves = (lds_v4f_ptr)lleaves;
+        if (with_light) {
+            lws.n_top = bvh_stage_top(lbv, lnodes, lbv.n_nodes);
+            bvh_stage_leaves(lbv, lleaves);
+        }
+        share = (lds_u8_ptr)share_mem + 128 * wv;
+    } else {
+        v4f *light_top = scene_mem + BVH_TOP_NODES * 4;
+        ws.n_top = bvh_stage_top(bv, scene_mem);
+        lws.top = (lds_v4f_ptr)light_top;
+        if (with_light) lws.n_top = bvh_stage_top(lbv, light_top, CFG::SHARE ? BVH_LIGHT_TOP_NODES - 16 : BVH_LIGHT_TOP_NODES);
+        share = (lds_u8_ptr)&light_top[(BVH_LIGHT_TOP_NODES - 16) * 4] + 128 * wv;
+    }
+}
+#define RT_TRAVERSAL_LDS(CFG)                                              \
+    __shared__ int stack_mem[CFG::STACK_INTS];                             \
+    __shared__ v4f scene_mem[CFG::SCENE_V4F];                              \
+    __shared__ unsigned char share_mem[CFG::SHARE_BYTES]
+
+// The three searches of a bounce in the form the kernel's configuration selects.
+template <class CFG>
+RT_DEV int closest_hit_cfg(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, const typename CFG::WS &ws, f4 &isec,
+                           BvhCounters &cnt) {
+    if (CFG::BVH) return closest_hit_bvh(sc, bv, ray, active, 0, sc.count, -1, 1.0f, ws, isec, cnt);
+    return closest_hit_bf(sc, ray, isec);
+}
+template <class CFG>
+RT_DEV bool shadow_any_hit_cfg(const DScene &sc, const DBvh &bv, const Ray &probe, float max_t, int current, bool run,
+                               const typename CFG::WS &ws, lds_u8_ptr share, BvhCounters &cnt) {
+    if (CFG::SHARE) return shadow_any_hit_shared<CFG::NODE_BUDGET>(sc, bv, probe, max_t, current, run, ws, share, cnt);
+    if (CFG::BVH) return shadow_any_hit_bvh(sc, bv, probe, max_t, current, run, ws, cnt);
+    return shadow_any_hit_bf(sc, probe, max_t, current, run);
+}
+template <class CFG>
+RT_DEV int glossy_search_cfg(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &probe, int current, bool run,
+                             int &light_id, f4 &lsec, const typename CFG::WS &ws, const typename CFG::WS &lws, lds_u8_ptr share,
+                             BvhCounters &cnt) {
+    if (CFG::SHARE) return glossy_search_shared<CFG::NODE_BUDGET>(sc, bv, lbv, probe, current, run, light_id, lsec, ws, lws, share, cnt);
+    if (CFG::BVH) return glossy_search_bvh(sc, bv, lbv, probe, current, run, light_id, lsec, ws, lws, cnt);
+    return glossy_search_bf(sc, probe, current, run, light_id, lsec);
+}
+
 // Queues without atomics.  Every pipeline kernel runs exactly PIPE_WAVES waves (in workgroups of WG_WAVES), and
 // wave v owns region v of every queue: it is the only one that appends to it (keeping the fill count
 // in a scalar register and storing it once at the end) and the only one that later consumes it.  A
@@ -80,7 +176,6 @@ struct PipeBuffers {
     uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
     uint32_t region_cap;
     unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
-    uint32_t *total;                            // scratch word for the early-stop read-back
 };
 
 enum { WSTAT_PATHS = 0, WSTAT_RAYS, WSTAT_SHADOW, WSTAT_GLOSSY, WSTAT_EXT_NODES, WSTAT_EXT_TRIS, WSTAT_PROBE_NODES,
@@ -141,10 +236,9 @@ struct RouteFill { uint32_t shadow, glossy, next; };
 // Shading of one path after its closest hit is known (raytracer.glsl:452-556): adds the sky on a
 // miss, otherwise runs shade_pre and hands the path to the shadow queue, the glossy queue or (no
 // probe needed) through the rest of the bounce to the next extend queue.  Called by whole waves.
-RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffers &b, int depth, int q_in,
-                            const uint32_t *__restrict__ coins, uint32_t paths_per_sample, int max_depth, bool live,
-                            uint32_t id, PathState &ps, uint32_t kept_flags, int hit, float hu, float hv, float ht,
-                            RouteFill &fill) {
+RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffers &b, int depth, int q_in, const PassTables &tab,
+                            uint32_t paths_per_sample, int max_depth, bool live, uint32_t id, PathState &ps, uint32_t kept_flags,
+                            int hit, float hu, float hv, float ht, RouteFill &fill) {
     bool to_shadow = false, to_glossy = false, go_on = false;
     Bounce bn;
     bn.kind = PROBE_NONE;
@@ -152,8 +246,8 @@ RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffer
         if (hit < 0) {
             ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
         } else {
-            const uint32_t slot = id / paths_per_sample;
-            const bool coin_diffuse = coins[slot * (uint32_t)max_depth + (uint32_t)depth] != 0u;
+            uint32_t ls = light_seed_at(tab.light_seed[id / paths_per_sample], depth);
+            const bool coin_diffuse = draw_coin(ls);
             shade_pre(sc, fr, ps, hit, hu, hv, ht, coin_diffuse, bn);
             if (bn.kind == PROBE_NONE) {
                 // sampleLight returned false before its occlusion loop: the kept light enters the roulette
@@ -174,7 +268,7 @@ RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffer
         b.pa[i] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
         b.pb[i] = make_float4(ps.d.y, ps.d.z, ps.path.x, ps.path.y);
         b.pc[i] = make_float4(ps.path.z, ps.energy.x, ps.energy.y, ps.energy.z);
-        b.pd[i] = make_uint4(ps.seed, id, (uint32_t)hit | (kept_flags << 30), 0xFFFFFFFFu);
+        b.pd[i] = make_uint4(ps.seed, id, (uint32_t)hit | (kept_flags << 30), 0u);
         b.p0[i] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
         if (to_shadow) {
             b.p1[i] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, bn.roughness);
@@ -195,16 +289,14 @@ RT_DEV void store_route_fill(const PipeBuffers &b, int q_in, const RouteFill &fi
     }
 }
 
-// Camera path of queue position `qi` at depth 0 (raytracer.glsl:586-607).  Returns false for the padding
-// lanes of ragged tiles.
-RT_DEV bool first_path(const DFrame &fr, const uint32_t *__restrict__ samples, uint32_t paths_per_sample, uint32_t tiles_x,
-                       uint32_t qi, bool live, PathState &ps) {
+// Camera path of queue position `qi` at depth 0 (raytracer.glsl:586-607); `sample` is the SAMPLE of its slot.
+// Returns false for the padding lanes of ragged tiles.
+RT_DEV bool first_path(const DFrame &fr, uint32_t sample, uint32_t in_sample, uint32_t tiles_x, bool live, PathState &ps) {
     const uint32_t lane = lane_index();
-    const uint32_t slot = live ? qi / paths_per_sample : 0u;
-    const uint32_t tile = (qi - slot * paths_per_sample) >> 6;
+    const uint32_t tile = in_sample >> 6;
     const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
     const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
-    ps.seed = pixel_seed(fr, tx, ty, samples[slot]);
+    ps.seed = pixel_seed(fr, tx, ty, sample);
     const Ray cam = camera_ray(fr, tx, ty, ps.seed);
     ps.o = cam.o; ps.d = cam.d;
     ps.path = mk3(1.0f, 1.0f, 1.0f);
@@ -212,70 +304,41 @@ RT_DEV bool first_path(const DFrame &fr, const uint32_t *__restrict__ samples, u
     return live && (tx < fr.width) && (ty < fr.height);
 }
 
-// Extend stage: the closest-hit search.  FIRST: depth 0, the wave generates the camera rays of its
-// pixels itself instead of reading a queue.  FUSED: the wave goes on to shade its paths; otherwise it
-// writes the hit record h0 = (u, v, t, triangle id; -1 = miss) and k_shade does the shading.  BVH:
-// hierarchy traversal instead of the loop over all triangles.
-template <bool FIRST, bool FUSED, bool BVH, int SHARE = 0>
-__global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
-                                                          const uint32_t *__restrict__ samples,
-                                                          const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
-                                                          uint32_t n_slots, int max_depth) {
+// Extend stage of the bounces after the first: closest hit of every path of the wave's queue region, then the
+// shading up to the probe loop (shade_and_route).
+template <class CFG>
+__global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
+                                                          PassTables tab, uint32_t paths_per_sample, int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
-    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][wave];
+    const uint32_t total = b.n_ext[q_in][wave];
     const size_t region = (size_t)wave * b.region_cap;
-    const uint32_t tiles_x = (fr.width + 7u) >> 3;
-    __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
-    __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
-    BvhScratch ws;
-    ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
-    ws.top = (lds_v4f_ptr)top_mem;
-    ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
-    __shared__ unsigned char share_mem[SHARE ? 128 * WG_WAVES : 1];
-    lds_u8_ptr share = (lds_u8_ptr)share_mem + (SHARE ? 128 * (threadIdx.x >> 6) : 0);
+    RT_TRAVERSAL_LDS(CFG);
+    typename CFG::WS ws, lws;
+    lds_u8_ptr share;
+    stage_hierarchies<CFG>(bv, bv, false, stack_mem, scene_mem, share_mem, ws, lws, share);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
-    uint32_t n_paths = 0, n_rays = 0;
+    uint32_t n_rays = 0;
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
 
-    // FIRST: chunks wave, wave + PIPE_WAVES, ... of the identity queue; else this wave's region
-    for (uint32_t base = FIRST ? wave * 64u : 0u; base < total; base += FIRST ? (uint32_t)PIPE_WAVES * 64u : 64u) {
+    for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t qi = base + lane;
-        bool live = qi < total;
+        const bool live = qi < total;
         uint32_t id = 0, kept_flags = 0;
         PathState ps;
-        if (FIRST) {
-            id = qi;
-            live = first_path(fr, samples, paths_per_sample, tiles_x, qi, live, ps);
-            n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
-        } else if (FUSED) {
-            load_path_rec(b, q_in, region + (live ? qi : 0u), ps, id, kept_flags);
-        } else {
-            const size_t i = region + (live ? qi : 0u);
-            const float4 a = b.xa[q_in][i], c = b.xb[q_in][i];
-            ps.o = mk3(a.x, a.y, a.z);
-            ps.d = mk3(a.w, c.x, c.y);
-        }
+        load_path_rec(b, q_in, region + (live ? qi : 0u), ps, id, kept_flags);
         n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
-        const int hit = SHARE ? closest_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, share, isec, bc)
-                        : BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, isec, bc)
-                            : closest_hit_bf(sc, ray, isec);
+        const int hit = closest_hit_cfg<CFG>(sc, bv, ray, live, ws, isec, bc);
         const float inv_det = 1.0f / isec.w;
-        if (FUSED) {
-            shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, kept_flags, hit,
-                            isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, fill);
-        } else if (live) {
-            b.h0[FIRST ? (size_t)qi : region + qi] =
-                make_float4(isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, __int_as_float(hit));
-        }
+        shade_and_route(sc, fr, b, depth, q_in, tab, paths_per_sample, max_depth, live, id, ps, kept_flags, hit,
+                        isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, fill);
     }
-    if (FUSED) store_route_fill(b, q_in, fill);
-    if (FIRST) wstat_add(b, WSTAT_PATHS, n_paths);
+    store_route_fill(b, q_in, fill);
     wstat_add(b, WSTAT_RAYS, n_rays);
-    if (BVH) {
+    if (CFG::BVH) {
         wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
         wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
     }
@@ -286,26 +349,17 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend(DScene sc, DBvh bv, DF
 // coin (raytracer.glsl:553: light_seed depends on SAMPLE and depth only) and run the same kind of probe, from
 // neighbouring surface points: the probe can run in place with full lanes, and the probe records (112 bytes
 // per path written and read back) are never made.  Deeper bounces mix samples in a wave and keep the queues.
-template <bool BVH, int SHARE = 0>
-__global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
-                                                         const uint32_t *__restrict__ samples,
-                                                         const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
-                                                         uint32_t n_slots, int max_depth) {
+template <class CFG>
+__global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void k_first(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
+                                                                              PassTables tab, uint32_t paths_per_sample,
+                                                                              int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
-    const uint32_t total = paths_per_sample * n_slots;
+    const uint32_t total = paths_per_sample * tab.n;
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
-    __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
-    __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
-    __shared__ v4f light_top_mem[BVH ? BVH_LIGHT_TOP_NODES * 4 : 1];
-    BvhScratch ws;
-    ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
-    ws.top = (lds_v4f_ptr)top_mem;
-    ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
-    BvhScratch lws = ws;
-    lws.top = (lds_v4f_ptr)light_top_mem;
-    // SHARE: the last 1 KB of the light hierarchy's cache holds 128 bytes per wave for anyhit_shared
-    lws.n_top = BVH ? bvh_stage_top(lbv, light_top_mem, SHARE ? BVH_LIGHT_TOP_NODES - 16 : BVH_LIGHT_TOP_NODES) : 0;
-    lds_u8_ptr share = (lds_u8_ptr)&light_top_mem[(BVH_LIGHT_TOP_NODES - 16) * 4] + 128 * (threadIdx.x >> 6);
+    RT_TRAVERSAL_LDS(CFG);
+    typename CFG::WS ws, lws;
+    lds_u8_ptr share;
+    stage_hierarchies<CFG>(bv, lbv, true, stack_mem, scene_mem, share_mem, ws, lws, share);
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
     uint32_t n_paths = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
@@ -323,17 +377,18 @@ __global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene s
         unsigned long long mark_ = __builtin_amdgcn_s_memtime();
 #endif
         const uint32_t id = base + lane;
+        // `base` lies in one sample's range of path ids: slot, SAMPLE and the coin are the same for the whole wave
+        const uint32_t slot = base / paths_per_sample;
         PathState ps;
-        const bool live = first_path(fr, samples, paths_per_sample, tiles_x, id, id < total, ps);
+        const bool live = first_path(fr, tab.sample[slot], base - slot * paths_per_sample, tiles_x, id < total, ps);
         n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
-        const int hit = BVH ? closest_hit_bvh(sc, bv, ray, live, 0, sc.count, -1, 1.0f, ws, isec, bc)
-                            : closest_hit_bf(sc, ray, isec);
+        const int hit = closest_hit_cfg<CFG>(sc, bv, ray, live, ws, isec, bc);
         SECTION_MARK(0);
         const float inv_det = 1.0f / isec.w;
-        // one coin for the whole wave: `base` lies in one sample's range of path ids
-        const bool coin_diffuse = coins[(base / paths_per_sample) * (uint32_t)max_depth] != 0u;
+        uint32_t ls = tab.light_seed[slot];
+        const bool coin_diffuse = draw_coin(ls);
         Bounce bn;
         bn.kind = PROBE_NONE; bn.max_t = 0.0f; bn.w = 0.0f; bn.roughness = 0.0f;
         bn.c = bn.lit = bn.albedo = bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
@@ -355,16 +410,15 @@ __global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene s
             const bool run = shaded && bn.kind == PROBE_SHADOW;
             bool blocked = true;
             if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                blocked = SHARE ? shadow_any_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, probe, bn.max_t, hit, run, ws, share, pc)
-                          : BVH ? shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run, ws, pc)
-                              : shadow_any_hit_bf(sc, probe, bn.max_t, hit, run);
+                blocked = shadow_any_hit_cfg<CFG>(sc, bv, probe, bn.max_t, hit, run, ws, share, pc);
                 n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             }
             SECTION_MARK(2);
             if (shaded) {
                 const bool written = run && !blocked;
-                if (written) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
                 go_on = finish_diffuse(sc, ps, hit, written, bn.lit, bn.albedo, bn.roughness) && deeper;
+                // the kept light result matters to later bounces only
+                if (written && go_on) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
             }
         } else {
             const bool run = shaded && bn.kind == PROBE_GLOSSY;
@@ -372,15 +426,13 @@ __global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene s
             f4 lsec;
             lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
             if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                outcome = SHARE ? glossy_search_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, share, pc)
-                          : BVH ? glossy_search_bvh(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, pc)
-                              : glossy_search_bf(sc, probe, hit, run, light_id, lsec);
+                outcome = glossy_search_cfg<CFG>(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, share, pc);
                 n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             }
             SECTION_MARK(RT_SECTION_CLOCKS == 2 ? 3 : 2);     // 2: the glossy probe is booked on the last slot
             if (shaded) {
                 go_on = finish_glossy(sc, fr, ps, hit, run ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w) && deeper;
-                if (run && outcome != 0) {
+                if (run && outcome != 0 && go_on) {
                     b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
                     kept_flags |= KEPT_SPEC;
                 }
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene s
     wstat_add(b, WSTAT_PROBE_NODES, clk[2]);
     wstat_add(b, WSTAT_PROBE_TRIS, clk[3]);
 #else
-    if (BVH) {
+    if (CFG::BVH) {
         wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
         wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(pc.nodes));
@@ -416,314 +468,29 @@ __global__ __launch_bounds__(64 * WG_WAVES, SHARE ? 4 : 1) void k_first(DScene s
 #undef SECTION_MARK
 }
 
-// Depth 0 with the light probes of a workgroup pooled.  In k_first a probe runs on the lane that shaded the
-// path: a third of the lanes has no probe (sky, emissive hits), and any-hit searches end at very different
-// times, so the probe loops run with 0.2-0.45 of their lanes doing work.  Here the 8 waves of a workgroup
-// put their probe rays (32 bytes each; the path state stays in the owner's registers) into a pool, meet at a
-// barrier, and then every wave draws rays from the pool: 64 at first, and as soon as POOL_REFILL_MIN lanes
-// have finished, that many new ones (bvh_advance keeps the others' traversal state).  A finished lane leaves a
-// one-word result in the pool record; after a second barrier the owners pick theirs up and go on with the bounce.
-// The pool lives in this workgroup's part of the probe-record arrays (unused at depth 0 otherwise); it is
-// written and read within microseconds by one CU, i.e. it lives in L2.  Two halves alternate from round to round, so
-// that a wave that is already appending for the next round cannot overwrite results a slower wave has yet to read.
-// A probe's result is a pure function of its ray, so the images are bit-identical to k_first's.
-// Measured on MI355X (option "pool", off by default): the probe loops' lane utilisation rises from 0.43 to 0.58
-// on a 424-triangle scene, but the kernel takes 9-20 % longer: a round's pool (at most 512 rays for 512 lanes)
-// is drawn empty by the first packets, so there is nothing to refill from, and the two barriers per round make
-// every wave wait for the workgroup's slowest tile twice.
-constexpr int POOL_REFILL_MIN = 24;
-constexpr uint32_t POOL_MIN_REGION = 128;      // two halves of 8 * region_cap / 2 >= 512 records
-
-RT_DEV bool ray_is_finite(const Ray &ray) {
-    const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
-    return (s - s) == 0.0f;
-}
-
-// One pass over a pool: `n_total` records at pool positions slot_of(0 .. n_total-1); `cursor` (LDS) hands them out.
-// load(slot) sets up the lane's probe; leaf/limit as for bvh_advance; store(slot) leaves the result.
-template <typename LoadFn, typename LeafFn, typename LimitFn, typename StoreFn>
-RT_DEV void pool_consume(const DBvh &bv, const BvhScratch &ws, uint32_t *cursor, uint32_t n_total, BvhRay &br, LoadFn load,
-                         LeafFn leaf, LimitFn limit, StoreFn store, BvhCounters &cnt) {
-    bool busy = false, exhausted = false;
-    uint32_t slot = 0;
-    TravState ts;
-    ts.node = 0; ts.sp = 0; ts.run = false;
-    for (;;) {
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (!exhausted && n_idle >= (uint32_t)POOL_REFILL_MIN) {
-            uint32_t start = 0;
-            if (lane_index() == 0) start = atomicAdd(cursor, n_idle);
-            start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
-            const uint32_t avail = start < n_total ? n_total - start : 0u;
-            const uint32_t take = n_idle < avail ? n_idle : avail;
-            exhausted = take < n_idle;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (!busy && rank < take) {
-                slot = start + rank;
-                load(slot);
-                busy = true;
-                ts.node = 0; ts.sp = 0; ts.run = true;
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
-        bvh_advance(bv, br, ws, ts, exhausted ? 65 : POOL_REFILL_MIN, leaf, limit, cnt);
-        if (busy && !ts.run) store(slot);
-        busy = busy && ts.run;
-    }
-}
-
-__global__ __launch_bounds__(64 * WG_WAVES, 4) void k_first_pool(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
-                                                              const uint32_t *__restrict__ samples,
-                                                              const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
-                                                              uint32_t n_slots, int max_depth) {
-    const uint32_t lane = lane_index(), wave = wave_index();
-    const uint32_t total = paths_per_sample * n_slots;
-    const uint32_t tiles_x = (fr.width + 7u) >> 3;
-    __shared__ int stack_mem[BVH_STACK * 64 * WG_WAVES];
-    __shared__ v4f top_mem[BVH_TOP_NODES * 4];
-    __shared__ v4f light_top_mem[BVH_LIGHT_TOP_NODES * 4];
-    // per half of the pool: shadow records, glossy records, shadow cursor, glossy cursor.  The 80 KB of the arrays
-    // above are exactly half of a CU's LDS, so these 32 bytes take the place of the light hierarchy's last cached node.
-    uint32_t (*pool_ctl)[4] = (uint32_t (*)[4])&light_top_mem[(BVH_LIGHT_TOP_NODES - 1) * 4];
-    if (threadIdx.x < 8) (&pool_ctl[0][0])[threadIdx.x] = 0u;
-    BvhScratch ws;
-    ws.stack = stack_mem + (threadIdx.x >> 6) * (BVH_STACK * 64) + lane;
-    ws.top = (lds_v4f_ptr)top_mem;
-    ws.n_top = bvh_stage_top(bv, top_mem);
-    BvhScratch lws = ws;
-    lws.top = (lds_v4f_ptr)light_top_mem;
-    lws.n_top = bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES - 1);
-    BvhCounters bc, pc;
-    bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
-    uint32_t n_paths = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
-    const bool deeper = 1 < max_depth;
-    const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
-    const uint32_t half = (uint32_t)WG_WAVES * b.region_cap / 2u;
-    const size_t pool0 = (size_t)blockIdx.x * WG_WAVES * b.region_cap;
-
-    uint32_t parity = 0;
-    for (uint32_t round = 0; (unsigned long long)round * PIPE_WAVES * 64ull < total; round++, parity ^= 1u) {
-        const unsigned long long base64 = ((unsigned long long)round * PIPE_WAVES + wave) * 64ull;
-        const bool in_range = base64 < total;            // wave-uniform; `total` is a multiple of 64
-        const uint32_t base = in_range ? (uint32_t)base64 : 0u;
-        const uint32_t id = base + lane;
-        // ---- camera ray, closest hit, shading up to the probe
-        PathState ps;
-        const bool live = first_path(fr, samples, paths_per_sample, tiles_x, id, in_range, ps);
-        n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
-        Ray ray; ray.o = ps.o; ray.d = ps.d;
-        f4 isec;
-        const int hit = closest_hit_bvh(sc, bv, ray, live, 0, count, -1, 1.0f, ws, isec, bc);
-        const float inv_det = 1.0f / isec.w;
-        const bool coin_diffuse = coins[(base / paths_per_sample) * (uint32_t)max_depth] != 0u;
-        Bounce bn;
-        bn.kind = PROBE_NONE; bn.max_t = 0.0f; bn.w = 0.0f; bn.roughness = 0.0f;
-        bn.c = bn.lit = bn.albedo = bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
-        bool shaded = false;
-        if (live) {
-            if (hit < 0) {
-                ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
-            } else {
-                shade_pre(sc, fr, ps, hit, isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, coin_diffuse, bn);
-                shaded = true;
-            }
-        }
-        Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
-        const bool finite = ray_is_finite(probe);
-        const bool run_s = shaded && coin_diffuse && bn.kind == PROBE_SHADOW;
-        const bool run_g = shaded && !coin_diffuse && bn.kind == PROBE_GLOSSY;
-        n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_s));
-        n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_g));
-        bool blocked = false;          // result of the any-hit search of either kind
-        // shadow probes the hierarchy cannot take (non-finite ray or range) go through the index-order loop here
-        const bool pool_s = run_s && finite && ((bn.max_t - bn.max_t) == 0.0f);
-        if (__builtin_amdgcn_ballot_w64(run_s && !pool_s) != 0ull) {
-            const bool b2 = shadow_any_hit_bf(sc, probe, bn.max_t, hit, run_s && !pool_s);
-            if (run_s && !pool_s) blocked = b2;
-        }
-        // glossy probes: the closest emissive triangle in place (a small hierarchy), the any-hit search pooled
-        int light_id = -1;
-        f4 lsec;
-        lsec.x = lsec.y = 0.0f; lsec.z = -1.0f; lsec.w = 0.0f;
-        bool pool_g = false;
-        if (__builtin_amdgcn_ballot_w64(run_g) != 0ull) {
-            if (lbv.enabled) {
-                light_id = closest_hit_bvh(sc, lbv, probe, run_g, 0, lights, hit, 0.0f, lws, lsec, pc);
-            } else {
-                light_id = closest_hit_range(sc.geo, 0, lights, probe, run_g, hit, lsec, -1);
-            }
-            const bool bounded = lsec.z >= 0.0f;
-            const float t_light = lsec.z / lsec.w;
-            const bool ok = finite && (!bounded || (t_light - t_light) == 0.0f);
-            const bool others = lights < count;
-            pool_g = run_g && ok && others;
-            const bool redo = run_g && !ok && others;
-            if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-                const bool b2 = closer_any_hit_range(sc.geo, lights, count, probe, lsec, hit, redo);
-                if (redo) blocked = b2;
-            }
-        }
-        // ---- append to the pool: shadow records from the front of this round's half, glossy records from its back
-        const size_t pool = pool0 + (size_t)parity * half;
-        uint32_t my_slot = 0;
-        {
-            const unsigned long long ms = __builtin_amdgcn_ballot_w64(pool_s), mg = __builtin_amdgcn_ballot_w64(pool_g);
-            uint32_t start_s = 0, start_g = 0;
-            if (lane == 0) {
-                if (ms) start_s = atomicAdd(&pool_ctl[parity][0], (uint32_t)__popcll(ms));
-                if (mg) start_g = atomicAdd(&pool_ctl[parity][1], (uint32_t)__popcll(mg));
-            }
-            start_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)start_s);
-            start_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)start_g);
-            if (pool_s) {
-                my_slot = start_s + __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
-                b.p0[pool + my_slot] = make_float4(probe.o.x, probe.o.y, probe.o.z, bn.max_t);
-                b.p1[pool + my_slot] = make_float4(probe.d.x, probe.d.y, probe.d.z, __int_as_float(hit));
-            }
-            if (pool_g) {
-                my_slot = half - 1u - (start_g + __builtin_amdgcn_mbcnt_hi((uint32_t)(mg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg, 0u)));
-                b.p0[pool + my_slot] = make_float4(probe.o.x, probe.o.y, probe.o.z, lsec.z);
-                b.p1[pool + my_slot] = make_float4(probe.d.x, probe.d.y, probe.d.z, __int_as_float(hit));
-                b.pd[pool + my_slot] = make_uint4(0u, __float_as_uint(lsec.w), 0u, 0u);
-            }
-        }
-        __syncthreads();
-        // the other half's counters were last read before the barrier every wave has just passed
-        if (threadIdx.x < 4) pool_ctl[parity ^ 1u][threadIdx.x] = 0u;
-        const uint32_t pool_ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_ctl[parity][0]);
-        const uint32_t pool_ng = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_ctl[parity][1]);
-        // ---- every wave draws from the pool
-        {
-            Ray pr;
-            pr.o = pr.d = mk3(0.0f, 0.0f, 0.0f);
-            float pmax = 0.0f, lim = 0.0f;
-            int pcur = -1;
-            bool pblocked = false;
-            f4 psec;
-            psec.x = psec.y = 0.0f; psec.z = -1.0f; psec.w = 0.0f;
-            BvhRay br = bvh_ray_setup(pr, bv.max_abs_coord);
-            if (pool_ns > 0u) {
-                auto load = [&](uint32_t slot) {
-                    const float4 a = b.p0[pool + slot], d = b.p1[pool + slot];
-                    pr.o = mk3(a.x, a.y, a.z); pr.d = mk3(d.x, d.y, d.z);
-                    pmax = a.w; pcur = __float_as_int(d.w);
-                    lim = pmax * BVH_NEAR;
-                    br = bvh_ray_setup(pr, bv.max_abs_coord);
-                    pblocked = false;
-                };
-                auto leaf = [&](int s) -> bool {
-                    const Tri t = load_leaf_tri(bv, s);
-                    if (intersect_triangle_shadow(pr, t, pmax) && leaf_tri_id(bv, s) != pcur) { pblocked = true; return false; }
-                    return true;
-                };
-                auto limit = [&]() -> float { return lim; };
-                auto store = [&](uint32_t slot) { ((uint32_t *)&b.pd[pool + slot])[0] = pblocked ? 1u : 0u; };
-                pool_consume(bv, ws, &pool_ctl[parity][2], pool_ns, br, load, leaf, limit, store, pc);
-            }
-            if (pool_ng > 0u) {
-                auto load = [&](uint32_t k) {
-                    const size_t i = pool + (half - 1u - k);
-                    const float4 a = b.p0[i], d = b.p1[i];
-                    pr.o = mk3(a.x, a.y, a.z); pr.d = mk3(d.x, d.y, d.z);
-                    pcur = __float_as_int(d.w);
-                    psec.z = a.w; psec.w = __uint_as_float(b.pd[i].y);
-                    const bool bounded = psec.z >= 0.0f;          // a light was hit: only triangles not farther than it matter
-                    lim = bounded ? (psec.z / psec.w) * BVH_NEAR : __builtin_inff();
-                    br = bvh_ray_setup(pr, bv.max_abs_coord);
-                    pblocked = false;
-                };
-                auto leaf = [&](int s) -> bool {
-                    const Tri t = load_leaf_tri(bv, s);
-                    PlaneTest pt;
-                    float rx, ry;
-                    if (plane_test_closest(pr, t, psec, pt) && inside_test(pr, t, pt, rx, ry)) {
-                        const int tid = leaf_tri_id(bv, s);
-                        if (tid >= lights && tid != pcur) { pblocked = true; return false; }
-                    }
-                    return true;
-                };
-                auto limit = [&]() -> float { return lim; };
-                auto store = [&](uint32_t k) { ((uint32_t *)&b.pd[pool + (half - 1u - k)])[0] = pblocked ? 1u : 0u; };
-                pool_consume(bv, ws, &pool_ctl[parity][3], pool_ng, br, load, leaf, limit, store, pc);
-            }
-        }
-        __syncthreads();
-        // ---- the owners pick up their results and finish the bounce
-        if (pool_s | pool_g) blocked = b.pd[pool + my_slot].x != 0u;
-        ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
-        uint32_t kept_flags = 0;
-        bool go_on = false;
-        if (shaded) {
-            if (coin_diffuse) {
-                const bool written = run_s && !blocked;
-                if (written) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
-                go_on = finish_diffuse(sc, ps, hit, written, bn.lit, bn.albedo, bn.roughness) && deeper;
-            } else {
-                const int outcome = run_g ? (blocked ? 0 : (light_id < 0 ? 1 : 2)) : 0;
-                go_on = finish_glossy(sc, fr, ps, hit, outcome, bn.probe_d, light_id, lsec, bn.c, bn.w) && deeper;
-                if (run_g && outcome != 0) {
-                    b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
-                    kept_flags |= KEPT_SPEC;
-                }
-            }
-        }
-        route_next(b, 1, fill_next, live, go_on, ps, id, kept_flags);
-    }
-    if (lane == 0) {
-        b.n_shadow[wave] = 0;
-        b.n_glossy[wave] = 0;
-        b.n_ext[1][wave] = fill_next;
-    }
-    wstat_add(b, WSTAT_PATHS, n_paths);
-    wstat_add(b, WSTAT_RAYS, n_paths);
-    wstat_add(b, WSTAT_DEPTH1, fill_next);
-    wstat_add(b, WSTAT_SHADOW, n_shadow);
-    wstat_add(b, WSTAT_GLOSSY, n_glossy);
-    wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
-    wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
-    wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(pc.nodes));
-    wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(pc.tris));
-}
-
 // The tail of the batch in one launch.  After a few bounces a small fraction of the paths is still under way, and
 // a stage of the pipeline over so few records takes as long as its chain of dependent memory accesses, whatever
-// the record count: 45-60 us per kernel plus launch gaps and the early-stop read-back, three kernels per depth
-// (12 depths of that are a fifth of a RECURSION 16 batch).  Here every lane walks the rest of its path: closest
-// hit, shading, probe in place, rest of the bounce, next bounce, as in the single-kernel form but starting from
-// the records of the extend queue and with the hierarchy.  Lanes of a wave end at different depths; a lane whose
-// path has ended takes the next record of the wave's region, so every bounce runs with a full wave until the
-// region is used up.  The kept light results stay in registers.
-#ifndef RT_TAIL_FIRST_CHECK
-#define RT_TAIL_FIRST_CHECK 2     // the host first looks at the queue size after this depth
-#endif
-// ONE: a single bounce of every path with its probe in place; the survivors go to the next extend queue.
-template <bool ONE, int SHARE>
-__global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth0,
-                                                           int q_in, const uint32_t *__restrict__ coins,
-                                                           uint32_t paths_per_sample, int max_depth) {
+// the record count: 45-60 us per kernel plus launch gaps, three kernels per depth (12 depths of that are a fifth of
+// a RECURSION 16 batch).  Here every lane walks the rest of its path: closest hit, shading, probe in place, rest of
+// the bounce, next bounce, as in the single-kernel form but starting from the records of the extend queue.  Lanes
+// of a wave end at different depths; a lane whose path has ended takes the next record of the wave's region, so
+// every bounce runs with a full wave until the region is used up.  The kept light results stay in registers.
+template <class CFG>
+__global__ __launch_bounds__(64 * WG_WAVES, RT_MIN_WAVES) void k_tail(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth0,
+                                                           int q_in, PassTables tab, uint32_t paths_per_sample, int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
-    __shared__ int stack_mem[BVH_STACK * 64 * WG_WAVES];
-    __shared__ v4f top_mem[BVH_TOP_NODES * 4];
-    __shared__ v4f light_top_mem[BVH_LIGHT_TOP_NODES * 4];
-    BvhScratch ws;
-    ws.stack = stack_mem + (threadIdx.x >> 6) * (BVH_STACK * 64) + lane;
-    ws.top = (lds_v4f_ptr)top_mem;
-    ws.n_top = bvh_stage_top(bv, top_mem);
-    BvhScratch lws = ws;
-    lws.top = (lds_v4f_ptr)light_top_mem;
-    // SHARE: the last 1 KB of the light hierarchy's cache holds 128 bytes per wave for anyhit_shared
-    lws.n_top = bvh_stage_top(lbv, light_top_mem, SHARE ? BVH_LIGHT_TOP_NODES - 16 : BVH_LIGHT_TOP_NODES);
-    lds_u8_ptr share = (lds_u8_ptr)&light_top_mem[(BVH_LIGHT_TOP_NODES - 16) * 4] + 128 * (threadIdx.x >> 6);
+    RT_TRAVERSAL_LDS(CFG);
+    typename CFG::WS ws, lws;
+    lds_u8_ptr share;
+    stage_hierarchies<CFG>(bv, lbv, true, stack_mem, scene_mem, share_mem, ws, lws, share);
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
-    uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
-    const int depth_end = ONE ? (depth0 + 1 < max_depth ? depth0 + 1 : max_depth) : max_depth;
+    uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0;
     const uint32_t total = b.n_ext[q_in][wave];
     const size_t region = (size_t)wave * b.region_cap;
     // per-lane state of the path a lane is walking
     PathState ps;
-    uint32_t id = 0, kept_flags = 0, coin_row = 0;
+    uint32_t id = 0, kept_flags = 0, light_seed = 0;
     bool alive = false;
     ps.o = ps.d = ps.path = ps.energy = ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
     ps.seed = 0;
@@ -732,16 +499,16 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
         ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
         if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
         if (kept_flags & KEPT_SPEC) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
-        coin_row = (id / paths_per_sample) * (uint32_t)max_depth;
+        light_seed = light_seed_at(tab.light_seed[id / paths_per_sample], depth0);
     };
     // one bounce of every lane with `alive`, each at its own `depth`
     auto bounce = [&](int depth) {
         n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(alive));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
-        const int hit = closest_hit_bvh(sc, bv, ray, alive, 0, sc.count, -1, 1.0f, ws, isec, bc);
+        const int hit = closest_hit_cfg<CFG>(sc, bv, ray, alive, ws, isec, bc);
         const float inv_det = 1.0f / isec.w;
-        const bool coin_diffuse = coins[alive ? coin_row + (uint32_t)depth : 0u] != 0u;     // idle lanes: any valid entry
+        const bool coin_diffuse = draw_coin(light_seed);
         Bounce bn;
         bn.kind = PROBE_NONE; bn.max_t = 0.0f; bn.w = 0.0f; bn.roughness = 0.0f;
         bn.c = bn.lit = bn.albedo = bn.probe_d = mk3(0.0f, 0.0f, 0.0f);
@@ -759,108 +526,75 @@ __global__ __launch_bounds__(64 * WG_WAVES, 4) void k_tail(DScene sc, DBvh bv, D
         const bool run_g = shaded && !coin_diffuse && bn.kind == PROBE_GLOSSY;
         bool blocked = true;
         if (__builtin_amdgcn_ballot_w64(run_s) != 0ull) {
-            blocked = SHARE ? shadow_any_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, probe, bn.max_t, hit, run_s, ws, share, pc)
-                            : shadow_any_hit_bvh(sc, bv, probe, bn.max_t, hit, run_s, ws, pc);
+            blocked = shadow_any_hit_cfg<CFG>(sc, bv, probe, bn.max_t, hit, run_s, ws, share, pc);
             n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_s));
         }
         int outcome = 0, light_id = -1;
         f4 lsec;
         lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
         if (__builtin_amdgcn_ballot_w64(run_g) != 0ull) {
-            outcome = SHARE ? glossy_search_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, share, pc)
-                            : glossy_search_bvh(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, pc);
+            outcome = glossy_search_cfg<CFG>(sc, bv, lbv, probe, hit, run_g, light_id, lsec, ws, lws, share, pc);
             n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run_g));
         }
         bool go_on = false;
         if (shaded) {
-            if (coin_diffuse) {
-                const bool written = run_s && !blocked;
-                go_on = finish_diffuse(sc, ps, hit, written, bn.lit, bn.albedo, bn.roughness);
-                if (ONE && written) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
-            } else {
-                go_on = finish_glossy(sc, fr, ps, hit, run_g ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
-                if (ONE && run_g && outcome != 0) {
-                    b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
-                    kept_flags |= KEPT_SPEC;
-                }
-            }
+            if (coin_diffuse) go_on = finish_diffuse(sc, ps, hit, run_s && !blocked, bn.lit, bn.albedo, bn.roughness);
+            else go_on = finish_glossy(sc, fr, ps, hit, run_g ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
         }
         go_on = go_on && (depth + 1 < max_depth);
         if (alive && !go_on) finish_path(b, id, ps);
         alive = alive && go_on;
     };
-    if (ONE) {
-        for (uint32_t base = 0; base < total; base += 64u) {
-            alive = base + lane < total;
-            if (alive) take_record(base + lane);
-            if (depth0 < depth_end) bounce(depth0);
-            // whole waves: the queue position comes from a ballot
-            const uint32_t slot = region_slot(fill_next, alive);
-            if (alive) store_path_rec(b, q_in ^ 1, region + slot, ps, id, kept_flags);
+    // Lanes whose path has ended take the next record of the region, so the wave stays full while lanes are at
+    // different depths of different paths.
+    uint32_t next = 0;
+    int depth = depth0;
+    for (;;) {
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
+        if (next < total && idle != 0ull) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t avail = total - next, n_idle = (uint32_t)__popcll(idle);
+            const uint32_t take = n_idle < avail ? n_idle : avail;
+            if (!alive && rank < take) { take_record(next + rank); depth = depth0; alive = depth0 < max_depth; }
+            next += take;
         }
-    } else {
-        // Lanes whose path has ended take the next record of the region, so the wave stays full while lanes are at
-        // different depths of different paths.
-        uint32_t next = 0;
-        int depth = depth0;
-        for (;;) {
-            const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
-            if (next < total && idle != 0ull) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                const uint32_t avail = total - next, n_idle = (uint32_t)__popcll(idle);
-                const uint32_t take = n_idle < avail ? n_idle : avail;
-                if (!alive && rank < take) { take_record(next + rank); depth = depth0; alive = depth0 < max_depth; }
-                next += take;
-            }
-            if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
-            bounce(depth);
-            depth++;
-        }
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
+        bounce(depth);
+        depth++;
     }
     if (lane == 0) {
         b.n_shadow[wave] = 0;
         b.n_glossy[wave] = 0;
-        b.n_ext[q_in ^ 1][wave] = fill_next;
+        b.n_ext[q_in ^ 1][wave] = 0;
     }
     wstat_add(b, WSTAT_RAYS, n_rays);
     wstat_add(b, WSTAT_SHADOW, n_shadow);
     wstat_add(b, WSTAT_GLOSSY, n_glossy);
-    wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
-    wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
-    wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(pc.nodes));
-    wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(pc.tris));
+    if (CFG::BVH) {
+        wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
+        wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
+        wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(pc.nodes));
+        wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(pc.tris));
+    }
 }
 
-// Shade stage of the unfused form.
-template <bool FIRST>
-__global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in,
-                                                         const uint32_t *__restrict__ samples,
-                                                         const uint32_t *__restrict__ coins, uint32_t paths_per_sample,
-                                                         uint32_t n_slots, int max_depth) {
+// Shading of the paths whose hit records the lane-refill form of the extend stage has left in h0.
+__global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in, PassTables tab,
+                                                         uint32_t paths_per_sample, int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
-    const uint32_t total = FIRST ? paths_per_sample * n_slots : b.n_ext[q_in][wave];
+    const uint32_t total = b.n_ext[q_in][wave];
     const size_t region = (size_t)wave * b.region_cap;
-    const uint32_t tiles_x = (fr.width + 7u) >> 3;
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
-
-    for (uint32_t base = FIRST ? wave * 64u : 0u; base < total; base += FIRST ? (uint32_t)PIPE_WAVES * 64u : 64u) {
+    for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t qi = base + lane;
-        bool live = qi < total;
+        const bool live = qi < total;
         uint32_t id = 0, kept_flags = 0;
         PathState ps;
-        size_t hi;
-        if (FIRST) {
-            // the camera ray is cheap to regenerate (raytracer.glsl:594-606): no state was stored for depth 0
-            id = live ? qi : 0u;
-            live = first_path(fr, samples, paths_per_sample, tiles_x, id, live, ps);
-            hi = id;
-        } else {
-            hi = region + (live ? qi : 0u);
-            load_path_rec(b, q_in, hi, ps, id, kept_flags);
-        }
+        const size_t hi = region + (live ? qi : 0u);
+        load_path_rec(b, q_in, hi, ps, id, kept_flags);
         const float4 h = b.h0[hi];
-        shade_and_route(sc, fr, b, depth, q_in, coins, paths_per_sample, max_depth, live, id, ps, kept_flags,
+        shade_and_route(sc, fr, b, depth, q_in, tab, paths_per_sample, max_depth, live, id, ps, kept_flags,
                         __float_as_int(h.w), h.x, h.y, h.z, fill);
     }
     store_route_fill(b, q_in, fill);
@@ -871,7 +605,7 @@ struct ProbeHead {
     Ray probe;
     float max_t;
     uint32_t seed, id, kept_flags;
-    int current, light_id;
+    int current;
 };
 RT_DEV void load_probe_head(const PipeBuffers &b, size_t i, ProbeHead &h) {
     const float4 a = b.pa[i], pr = b.p0[i];
@@ -883,35 +617,35 @@ RT_DEV void load_probe_head(const PipeBuffers &b, size_t i, ProbeHead &h) {
     h.id = d.y;
     h.current = (int)(d.z & CURRENT_MASK);
     h.kept_flags = d.z >> 30;
-    h.light_id = (int)d.w;
 }
-// Rest of a bounce after its shadow probe (raytracer.glsl:557-579).  Returns whether the path goes on.
-RT_DEV bool retire_shadow(const DScene &sc, const PipeBuffers &b, size_t i, const ProbeHead &h, bool blocked, PathState &ps,
-                          uint32_t &kept_flags) {
+// Rest of a bounce after its shadow probe (raytracer.glsl:557-579).  Returns whether the path goes on; only then is
+// the kept light result stored (nothing reads it otherwise).
+RT_DEV bool retire_shadow(const DScene &sc, const PipeBuffers &b, size_t i, const ProbeHead &h, bool blocked, bool deeper,
+                          PathState &ps, uint32_t &kept_flags) {
     load_probe_path(b, i, ps);
     ps.seed = h.seed;
     const float4 c = b.p1[i], al = b.p2[i];
     kept_flags = h.kept_flags;
     ps.kept_diff = mk3(0.0f, 0.0f, 0.0f);
-    if (blocked) {
-        if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[h.id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
-    } else {
+    if (blocked && (kept_flags & KEPT_DIFF)) { const float4 k = b.kd[h.id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
+    const bool go_on = finish_diffuse(sc, ps, h.current, !blocked, mk3(c.x, c.y, c.z), mk3(al.x, al.y, al.z), c.w) && deeper;
+    if (!blocked && go_on) {
         b.kd[h.id] = make_float4(c.x, c.y, c.z, 0.0f);
         kept_flags |= KEPT_DIFF;
     }
-    return finish_diffuse(sc, ps, h.current, !blocked, mk3(c.x, c.y, c.z), mk3(al.x, al.y, al.z), c.w);
+    return go_on;
 }
 // Rest of a bounce after its glossy probe (raytracer.glsl:420-437, :557-579).
 RT_DEV bool retire_glossy(const DScene &sc, const DFrame &fr, const PipeBuffers &b, size_t i, const ProbeHead &h, int outcome,
-                          int light_id, f4 lsec, PathState &ps, uint32_t &kept_flags) {
+                          int light_id, f4 lsec, bool deeper, PathState &ps, uint32_t &kept_flags) {
     load_probe_path(b, i, ps);
     ps.seed = h.seed;
     const float4 c = b.p1[i];
     kept_flags = h.kept_flags;
     ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
     if (outcome == 0 && (kept_flags & KEPT_SPEC)) { const float4 k = b.ks[h.id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
-    const bool go_on = finish_glossy(sc, fr, ps, h.current, outcome, h.probe.d, light_id, lsec, mk3(c.x, c.y, c.z), c.w);
-    if (outcome != 0) {
+    const bool go_on = finish_glossy(sc, fr, ps, h.current, outcome, h.probe.d, light_id, lsec, mk3(c.x, c.y, c.z), c.w) && deeper;
+    if (outcome != 0 && go_on) {
         b.ks[h.id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
         kept_flags |= KEPT_SPEC;
     }
@@ -919,18 +653,14 @@ RT_DEV bool retire_glossy(const DScene &sc, const DFrame &fr, const PipeBuffers 
 }
 
 // Shadow-probe stage: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579.
-template <bool BVH, int SHARE = 0>
-__global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in,
+template <class CFG>
+__global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in,
                                                                 int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
-    __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
-    __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
-    BvhScratch ws;
-    ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
-    ws.top = (lds_v4f_ptr)top_mem;
-    ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
-    __shared__ unsigned char share_mem[SHARE ? 128 * WG_WAVES : 1];
-    lds_u8_ptr share = (lds_u8_ptr)share_mem + (SHARE ? 128 * (threadIdx.x >> 6) : 0);
+    RT_TRAVERSAL_LDS(CFG);
+    typename CFG::WS ws, lws;
+    lds_u8_ptr share;
+    stage_hierarchies<CFG>(bv, bv, false, stack_mem, scene_mem, share_mem, ws, lws, share);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const size_t region = (size_t)wave * b.region_cap;
@@ -942,40 +672,30 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_shadow(DScene sc, DBvh 
         const size_t i = region + (live ? base + lane : 0u);
         ProbeHead h;
         load_probe_head(b, i, h);
-        const bool blocked = SHARE ? shadow_any_hit_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, h.probe, h.max_t, h.current, live, ws, share, bc)
-                             : BVH ? shadow_any_hit_bvh(sc, bv, h.probe, h.max_t, h.current, live, ws, bc)
-                                 : shadow_any_hit_bf(sc, h.probe, h.max_t, h.current, live);
+        const bool blocked = shadow_any_hit_cfg<CFG>(sc, bv, h.probe, h.max_t, h.current, live, ws, share, bc);
         PathState ps;
         uint32_t kept_flags = 0;
         bool go_on = false;
-        if (live) go_on = retire_shadow(sc, b, i, h, blocked, ps, kept_flags) && deeper;
+        if (live) go_on = retire_shadow(sc, b, i, h, blocked, deeper, ps, kept_flags);
         route_next(b, q_in ^ 1, fill_next, live, go_on, ps, h.id, kept_flags);
     }
     if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
     wstat_add(b, WSTAT_SHADOW, total);
-    if (BVH) {
+    if (CFG::BVH) {
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
         wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(bc.tris));
     }
 }
 
 // Glossy-probe stage: search of sampleLightGlossy (raytracer.glsl:403-437), then :557-579.
-template <bool BVH, int SHARE = 0>
-__global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
+template <class CFG>
+__global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
                                                                 int depth, int q_in, int max_depth) {
     const uint32_t lane = lane_index(), wave = wave_index();
-    __shared__ int stack_mem[BVH ? BVH_STACK * 64 * WG_WAVES : 64];
-    __shared__ v4f top_mem[BVH ? BVH_TOP_NODES * 4 : 1];
-    BvhScratch ws;
-    ws.stack = stack_mem + (BVH ? (threadIdx.x >> 6) * (BVH_STACK * 64) + lane : 0);
-    ws.top = (lds_v4f_ptr)top_mem;
-    ws.n_top = BVH ? bvh_stage_top(bv, top_mem) : 0;
-    __shared__ v4f light_top_mem[BVH ? BVH_LIGHT_TOP_NODES * 4 : 1];
-    BvhScratch lws = ws;
-    lws.top = (lds_v4f_ptr)light_top_mem;
-    // SHARE: the last 1 KB of the light hierarchy's cache holds 128 bytes per wave for anyhit_shared
-    lws.n_top = BVH ? bvh_stage_top(lbv, light_top_mem, SHARE ? BVH_LIGHT_TOP_NODES - 16 : BVH_LIGHT_TOP_NODES) : 0;
-    lds_u8_ptr share = (lds_u8_ptr)&light_top_mem[BVH ? (BVH_LIGHT_TOP_NODES - 16) * 4 : 0] + (SHARE ? 128 * (threadIdx.x >> 6) : 0);
+    RT_TRAVERSAL_LDS(CFG);
+    typename CFG::WS ws, lws;
+    lds_u8_ptr share;
+    stage_hierarchies<CFG>(bv, lbv, true, stack_mem, scene_mem, share_mem, ws, lws, share);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const size_t region = (size_t)wave * b.region_cap;
@@ -990,28 +710,26 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_probe_glossy(DScene sc, DBvh 
         load_probe_head(b, i, h);
         int light_id;
         f4 lsec;
-        const int outcome = SHARE ? glossy_search_shared<SHARE == 2 ? SHARE_NODE_BUDGET : 0>(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, share, bc)
-                            : BVH ? glossy_search_bvh(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, bc)
-                                : glossy_search_bf(sc, h.probe, h.current, live, light_id, lsec);
+        const int outcome = glossy_search_cfg<CFG>(sc, bv, lbv, h.probe, h.current, live, light_id, lsec, ws, lws, share, bc);
         PathState ps;
         uint32_t kept_flags = 0;
         bool go_on = false;
-        if (live) go_on = retire_glossy(sc, fr, b, i, h, outcome, light_id, lsec, ps, kept_flags) && deeper;
+        if (live) go_on = retire_glossy(sc, fr, b, i, h, outcome, light_id, lsec, deeper, ps, kept_flags);
         route_next(b, q_in ^ 1, fill_next, live, go_on, ps, h.id, kept_flags);
     }
     if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
     wstat_add(b, WSTAT_GLOSSY, total);
-    if (BVH) {
+    if (CFG::BVH) {
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
         wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(bc.tris));
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Traversal stages with lane refill.  Rays that start on surfaces are incoherent: in a wave that takes 64
-// queue entries and waits for the slowest, under a third of the lanes do useful work in the node loop.
-// Here a wave keeps its lanes busy instead: as soon as REFILL_MIN lanes have finished their ray, their
-// results are retired and the free lanes take the next records of the wave's queue region while the other
+// Extend stage with lane refill.  Rays that start on surfaces are incoherent: in a wave that takes 64
+// queue entries and waits for the slowest, under a third of the lanes do useful work in the node loop of a
+// large scene.  Here a wave keeps its lanes busy instead: as soon as REFILL_MIN lanes have finished their ray,
+// their results are retired and the free lanes take the next records of the wave's queue region while the other
 // lanes carry on where they were (bvh_advance keeps per-lane traversal state).  A path's arithmetic does
 // not depend on which lane or in which order it is processed, and the order of a queue region only
 // decides the order of the next region, so results stay bit-identical.
@@ -1036,201 +754,15 @@ RT_DEV bool refill_take(uint32_t total, uint32_t &next, bool busy, uint32_t &k) 
     return got;
 }
 
-// All light probes of one depth in one launch: the shadow records, then the glossy records in two passes
-// (closest light through the hierarchy over the emissive triangles; then the any-hit search over the
-// others, raytracer.glsl:403-419 in the two-phase form of glossy_search_bf).
-__global__ __launch_bounds__(64 * WG_WAVES) void k_probe_refill(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth,
-                                                                int q_in, int max_depth) {
-    const uint32_t lane = lane_index(), wave = wave_index();
-    __shared__ int stack_mem[BVH_STACK * 64 * WG_WAVES];
-    __shared__ v4f top_mem[BVH_TOP_NODES * 4];
-    BvhScratch ws;
-    ws.stack = stack_mem + (threadIdx.x >> 6) * (BVH_STACK * 64) + lane;
-    ws.top = (lds_v4f_ptr)top_mem;
-    ws.n_top = bvh_stage_top(bv, top_mem);
-    __shared__ v4f light_top_mem[BVH_LIGHT_TOP_NODES * 4];
-    BvhScratch lws = ws;
-    lws.top = (lds_v4f_ptr)light_top_mem;
-    lws.n_top = bvh_stage_top(lbv, light_top_mem, BVH_LIGHT_TOP_NODES);
-    BvhCounters bc;
-    bc.nodes = 0; bc.tris = 0;
-    const size_t region = (size_t)wave * b.region_cap;
-    const size_t last = region + b.region_cap - 1u;
-    uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
-    const bool deeper = depth + 1 < max_depth;
-    const int count = sc.count, lights = sc.lights < sc.count ? sc.lights : sc.count;
-    ProbeHead h;
-    h.probe.o = h.probe.d = mk3(0.0f, 0.0f, 0.0f);
-    h.max_t = 0.0f; h.seed = 0; h.id = 0; h.kept_flags = 0; h.current = -1; h.light_id = -1;
-
-    // ---- shadow records: occlusion query of sampleLight (raytracer.glsl:372-378), then :557-579
-    {
-        const uint32_t total = b.n_shadow[wave];
-        uint32_t next = 0;
-        size_t i = region;
-        bool busy = false, ok = true, blocked = false;
-        TravState ts;
-        ts.node = 0; ts.sp = 0; ts.run = false;
-        BvhRay br = bvh_ray_setup(h.probe, bv.max_abs_coord);
-        for (;;) {
-            uint32_t k = 0;
-            if (refill_take(total, next, busy, k)) {
-                i = region + k;
-                load_probe_head(b, i, h);
-                br = bvh_ray_setup(h.probe, bv.max_abs_coord);
-                ok = br.finite && ((h.max_t - h.max_t) == 0.0f);
-                blocked = false;
-                busy = true;
-                ts.node = 0; ts.sp = 0; ts.run = ok;
-            }
-            if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
-            auto leaf = [&](int slot) -> bool {
-                const Tri t = load_leaf_tri(bv, slot);
-                if (intersect_triangle_shadow(h.probe, t, h.max_t) && leaf_tri_id(bv, slot) != h.current) { blocked = true; return false; }
-                return true;
-            };
-            const float lim = h.max_t * BVH_NEAR;
-            auto limit = [&]() -> float { return lim; };
-            bvh_advance(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
-            const bool fin = busy && !ts.run;
-            const bool redo = fin && !ok;
-            if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-                const bool b2 = shadow_any_hit_bf(sc, h.probe, h.max_t, h.current, redo);
-                if (redo) blocked = b2;
-            }
-            PathState ps;
-            uint32_t kept_flags = 0;
-            bool go_on = false;
-            if (fin) go_on = retire_shadow(sc, b, i, h, blocked, ps, kept_flags) && deeper;
-            route_next(b, q_in ^ 1, fill_next, fin, go_on, ps, h.id, kept_flags);
-            busy = busy && ts.run;
-        }
-        wstat_add(b, WSTAT_SHADOW, total);
-    }
-
-    // ---- glossy records, pass 1: closest emissive triangle -> p2 = its (x, y, rd, det), pd.w = its index
-    const uint32_t g_total = b.n_glossy[wave];
-    if (lbv.enabled) {
-        uint32_t next = 0;
-        size_t i = last;
-        bool busy = false;
-        TravState ts;
-        ts.node = 0; ts.sp = 0; ts.run = false;
-        BvhRay br = bvh_ray_setup(h.probe, lbv.max_abs_coord);
-        ClosestFold cf;
-        closest_fold_reset(cf, 0.0f);
-        for (;;) {
-            uint32_t k = 0;
-            if (refill_take(g_total, next, busy, k)) {
-                i = last - k;
-                load_probe_head(b, i, h);
-                br = bvh_ray_setup(h.probe, lbv.max_abs_coord);
-                closest_fold_reset(cf, 0.0f);
-                busy = true;
-                ts.node = 0; ts.sp = 0; ts.run = br.finite;
-            }
-            if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
-            auto leaf = [&](int slot) -> bool { closest_fold_leaf(lbv, h.probe, slot, 0, lights, h.current, cf); return true; };
-            auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
-            bvh_advance(lbv, br, lws, ts, next < g_total ? REFILL_MIN : 65, leaf, limit, bc);
-            const bool fin = busy && !ts.run;
-            closest_fold_redo(sc, h.probe, fin && (!br.finite || cf.n_near > 2), 0, lights, h.current, 0.0f, cf);
-            if (fin) {
-                b.p2[i] = make_float4(cf.st.x, cf.st.y, cf.st.z, cf.st.w);
-                ((uint32_t *)&b.pd[i])[3] = (uint32_t)cf.best;
-            }
-            busy = busy && ts.run;
-        }
-    } else {
-        for (uint32_t base = 0; base < g_total; base += 64u) {
-            const bool live = base + lane < g_total;
-            const size_t i = last - (live ? base + lane : 0u);
-            load_probe_head(b, i, h);
-            f4 isec;
-            isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
-            const int light_id = closest_hit_range(sc.geo, 0, lights, h.probe, live, h.current, isec, -1);
-            if (live) {
-                b.p2[i] = make_float4(isec.x, isec.y, isec.z, isec.w);
-                ((uint32_t *)&b.pd[i])[3] = (uint32_t)light_id;
-            }
-        }
-    }
-    // the records of pass 1 are read back by other lanes of this wave: make them visible
-    __threadfence();
-
-    // ---- glossy records, pass 2: is any non-emissive triangle not farther than that light?  then :420-437, :557-579
-    {
-        uint32_t next = 0;
-        size_t i = last;
-        bool busy = false, ok = true, blocked = false;
-        TravState ts;
-        ts.node = 0; ts.sp = 0; ts.run = false;
-        f4 isec;
-        isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 0.0f;
-        float lim = 0.0f;
-        BvhRay br = bvh_ray_setup(h.probe, bv.max_abs_coord);
-        for (;;) {
-            uint32_t k = 0;
-            if (refill_take(g_total, next, busy, k)) {
-                i = last - k;
-                load_probe_head(b, i, h);
-                const float4 ls = b.p2[i];
-                isec.x = ls.x; isec.y = ls.y; isec.z = ls.z; isec.w = ls.w;
-                br = bvh_ray_setup(h.probe, bv.max_abs_coord);
-                const bool bounded = isec.z >= 0.0f;       // a light was hit: only triangles not farther than it matter
-                const float t_light = isec.z / isec.w;
-                ok = br.finite && (!bounded || (t_light - t_light) == 0.0f);
-                lim = bounded ? t_light * BVH_NEAR : __builtin_inff();
-                blocked = false;
-                busy = true;
-                ts.node = 0; ts.sp = 0; ts.run = ok && (lights < count);
-            }
-            if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
-            auto leaf = [&](int slot) -> bool {
-                const Tri t = load_leaf_tri(bv, slot);
-                PlaneTest pt;
-                float rx, ry;
-                if (plane_test_closest(h.probe, t, isec, pt) && inside_test(h.probe, t, pt, rx, ry)) {
-                    const int tid = leaf_tri_id(bv, slot);
-                    if (tid >= lights && tid != h.current) { blocked = true; return false; }
-                }
-                return true;
-            };
-            auto limit = [&]() -> float { return lim; };
-            bvh_advance(bv, br, ws, ts, next < g_total ? REFILL_MIN : 65, leaf, limit, bc);
-            const bool fin = busy && !ts.run;
-            const bool redo = fin && !ok && (lights < count);
-            if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
-                const bool b2 = closer_any_hit_range(sc.geo, lights, count, h.probe, isec, h.current, redo);
-                if (redo) blocked = b2;
-            }
-            PathState ps;
-            uint32_t kept_flags = 0;
-            bool go_on = false;
-            if (fin) {
-                const int outcome = blocked ? 0 : (h.light_id < 0 ? 1 : 2);
-                go_on = retire_glossy(sc, fr, b, i, h, outcome, h.light_id, isec, ps, kept_flags) && deeper;
-            }
-            route_next(b, q_in ^ 1, fill_next, fin, go_on, ps, h.id, kept_flags);
-            busy = busy && ts.run;
-        }
-        wstat_add(b, WSTAT_GLOSSY, g_total);
-    }
-    if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
-    wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
-    wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(bc.tris));
-}
-
-// Extend stage for depth >= 1 with lane refill: the closest-hit search alone; it leaves the hit record
-// h0 = (u, v, t, triangle id; -1 = miss) beside each path record and k_shade does the shading with full waves.
-__global__ __launch_bounds__(64 * WG_WAVES) void k_extend_refill(DScene sc, DBvh bv, PipeBuffers b, int q_in) {
-    const uint32_t lane = lane_index(), wave = wave_index();
-    __shared__ int stack_mem[BVH_STACK * 64 * WG_WAVES];
-    __shared__ v4f top_mem[BVH_TOP_NODES * 4];
-    BvhScratch ws;
-    ws.stack = stack_mem + (threadIdx.x >> 6) * (BVH_STACK * 64) + lane;
-    ws.top = (lds_v4f_ptr)top_mem;
-    ws.n_top = bvh_stage_top(bv, top_mem);
+// The closest-hit search alone; it leaves the hit record h0 = (u, v, t, triangle id; -1 = miss) beside each path
+// record and k_shade does the shading with full waves.
+template <class CFG>
+__global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_extend_refill(DScene sc, DBvh bv, PipeBuffers b, int q_in) {
+    const uint32_t wave = wave_index();
+    RT_TRAVERSAL_LDS(CFG);
+    typename CFG::WS ws, lws;
+    lds_u8_ptr share;
+    stage_hierarchies<CFG>(bv, bv, false, stack_mem, scene_mem, share_mem, ws, lws, share);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     const uint32_t total = b.n_ext[q_in][wave];
@@ -1258,7 +790,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend_refill(DScene sc, DBvh
             ts.node = 0; ts.sp = 0; ts.run = br.finite;
         }
         if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
-        auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ray, slot, 0, sc.count, -1, cf); return true; };
+        auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, 0, sc.count, -1, cf); return true; };
         auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
         bvh_advance(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
         const bool fin = busy && !ts.run;
@@ -1272,17 +804,6 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_extend_refill(DScene sc, DBvh
     wstat_add(b, WSTAT_RAYS, total);
     wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
     wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
-}
-
-// Sum of one array of region fill counts (for the host's early stop).
-__global__ __launch_bounds__(256) void k_sum_counts(const uint32_t *__restrict__ counts, int n, uint32_t *__restrict__ out) {
-    __shared__ uint32_t part[4];
-    uint32_t v = 0;
-    for (int i = threadIdx.x; i < n; i += 256) v += counts[i];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = part[0] + part[1] + part[2] + part[3];
 }
 
 // Resolve stage: sum[pixel] += radiance of the batch's samples, ascending slot order.
@@ -1301,25 +822,25 @@ __global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restri
     sum[pix] = s;
 }
 
+// What a pass may use, decided by the caller from the scene and the options.
+struct PassForm {
+    bool bvh;            // hierarchies are there and wanted
+    bool resident;       // ... and fit the LDS of a workgroup (KernelCfg::RES)
+    bool share;          // shared any-hit searches
+    bool refill;         // lane-refill form of the extend stage
+    int staged_depths;   // bounces after the first that run as staged kernels before the tail kernel takes the rest; < 0: all
+};
+
 // Host side of the pipeline: buffers sized for one batch, and the launch sequence.
 struct Pipeline {
     PipeBuffers buf = {};
     size_t cap_paths = 0;
-    uint32_t *d_coins = nullptr;
-    size_t cap_coins = 0;
-    // pinned staging for the coin table, two slots used in turn: the upload of a pass is queued behind the previous
-    // pass's kernels, so the host must not overwrite a slot before its copy has run (the slot's event tells)
-    uint32_t *h_coins[2] = {nullptr, nullptr};
-    hipEvent_t coins_copied[2] = {nullptr, nullptr};
-    int coin_slot = 0;
-    uint32_t *h_count = nullptr;   // pinned, for the early-stop read-back
+    bool have_h0 = false;
     // Profiling: events are recorded around every stage launch and turned into times lazily
     // (collect_times), so that the timed region carries no extra synchronisation.
     std::vector<hipEvent_t> events;
     std::vector<int> kinds;        // interval i = [event i, event i+1]: 0 extend, 3 extend at depth 0, 1 probes, 2 shade, -1 not counted
     size_t ev_used = 0;
-    // light seeds are also needed on the host to tabulate the per-depth coin; set before run()
-    std::vector<uint32_t> h_light_seeds;
 
     std::vector<void **> path_buffers() {
         return {(void **)&buf.xa[0], (void **)&buf.xa[1], (void **)&buf.xb[0], (void **)&buf.xb[1], (void **)&buf.xc[0],
@@ -1327,56 +848,54 @@ struct Pipeline {
                 (void **)&buf.pc, (void **)&buf.pd, (void **)&buf.p0, (void **)&buf.p1, (void **)&buf.p2, (void **)&buf.h0,
                 (void **)&buf.energy, (void **)&buf.kd, (void **)&buf.ks};
     }
+    std::vector<void **> counter_buffers() {
+        return {(void **)&buf.wstats, (void **)&buf.n_ext[0], (void **)&buf.n_ext[1], (void **)&buf.n_shadow, (void **)&buf.n_glossy};
+    }
 
     void free_paths() {
         for (void **p : path_buffers()) { (void)hipFree(*p); *p = nullptr; }
         cap_paths = 0;
+        have_h0 = false;
     }
 
     void release() {
         free_paths();
-        (void)hipFree(buf.n_ext[0]); (void)hipFree(buf.n_ext[1]); (void)hipFree(buf.n_shadow); (void)hipFree(buf.n_glossy);
-        (void)hipFree(buf.wstats); (void)hipFree(buf.total);
-        (void)hipFree(d_coins);
-        for (int k = 0; k < 2; k++) {
-            if (h_coins[k]) (void)hipHostFree(h_coins[k]);
-            if (coins_copied[k]) (void)hipEventDestroy(coins_copied[k]);
-            h_coins[k] = nullptr;
-            coins_copied[k] = nullptr;
-        }
-        if (h_count) (void)hipHostFree(h_count);
+        for (void **p : counter_buffers()) { (void)hipFree(*p); *p = nullptr; }
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         events.clear();
         buf = PipeBuffers{};
-        d_coins = nullptr;
-        h_count = nullptr;
-        cap_coins = 0;
     }
 
+    // A wave can never emit more entries than it consumed, so ceil(chunks / PIPE_WAVES) * 64 entries per region suffice.
     static uint32_t region_cap_for(size_t paths) {
         const size_t chunks = (paths + 63) / 64;
         const uint32_t cap = (uint32_t)(((chunks + PIPE_WAVES - 1) / PIPE_WAVES) * 64);
-        return cap < POOL_MIN_REGION ? POOL_MIN_REGION : cap;     // k_first_pool keeps a workgroup's probe pool in 8 regions
+        return cap < 64u ? 64u : cap;
     }
+    // Device memory of the queues of a pass of `paths` pixel-samples.
+    static size_t queue_bytes_for(size_t paths, bool with_h0) {
+        const size_t qn = (size_t)region_cap_for(paths) * PIPE_WAVES;
+        return qn * (2 * 64 + 112 + (with_h0 ? 16 : 0)) + paths * 48;
+    }
+    size_t queue_bytes() const { return cap_paths ? queue_bytes_for(cap_paths, have_h0) : 0; }
 
-    hipError_t ensure(size_t paths, size_t coins, const char **what) {
+    hipError_t ensure(size_t paths, bool need_h0, const char **what) {
         hipError_t e = hipSuccess;
-#define PIPE_ALLOC(ptr, bytes) do { *what = #ptr; e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
+#define PIPE_ALLOC(ptr, bytes) do { *what = #ptr; e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) goto failed; } while (0)
         if (!buf.wstats) {
             PIPE_ALLOC(buf.wstats, sizeof(unsigned long long) * WSTAT_SLOTS * PIPE_WAVES);
             *what = "memset wstats";
             e = hipMemset(buf.wstats, 0, sizeof(unsigned long long) * WSTAT_SLOTS * PIPE_WAVES);
-            if (e != hipSuccess) return e;
+            if (e != hipSuccess) goto failed;
             PIPE_ALLOC(buf.n_ext[0], sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_ext[1], sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_shadow, sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_glossy, sizeof(uint32_t) * PIPE_WAVES);
-            PIPE_ALLOC(buf.total, sizeof(uint32_t) * 4);
         }
-        if (paths > cap_paths) {
+        if (paths > cap_paths || (need_h0 && !have_h0)) {
+            const size_t want = paths > cap_paths ? paths : cap_paths;
             free_paths();
-            // queue planes hold PIPE_WAVES regions; h0 is indexed by path id at depth 0 and by queue position later
-            const size_t qn = (size_t)region_cap_for(paths) * PIPE_WAVES;
+            const size_t qn = (size_t)region_cap_for(want) * PIPE_WAVES;      // queue planes hold PIPE_WAVES regions
             for (int k = 0; k < 2; k++) {
                 PIPE_ALLOC(buf.xa[k], sizeof(float4) * qn);
                 PIPE_ALLOC(buf.xb[k], sizeof(float4) * qn);
@@ -1390,38 +909,20 @@ struct Pipeline {
             PIPE_ALLOC(buf.p0, sizeof(float4) * qn);
             PIPE_ALLOC(buf.p1, sizeof(float4) * qn);
             PIPE_ALLOC(buf.p2, sizeof(float4) * qn);
-            PIPE_ALLOC(buf.h0, sizeof(float4) * qn);
-            PIPE_ALLOC(buf.energy, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.kd, sizeof(float4) * paths);
-            PIPE_ALLOC(buf.ks, sizeof(float4) * paths);
-            cap_paths = paths;
-        }
-        if (coins > cap_coins) {
-            (void)hipFree(d_coins);
-            d_coins = nullptr;
-            cap_coins = 0;
-            PIPE_ALLOC(d_coins, sizeof(uint32_t) * coins);
-            for (int k = 0; k < 2; k++) {
-                if (h_coins[k]) (void)hipHostFree(h_coins[k]);      // hipFree above has drained the device
-                h_coins[k] = nullptr;
-                *what = "h_coins";
-                e = hipHostMalloc((void **)&h_coins[k], sizeof(uint32_t) * coins);
-                if (e != hipSuccess) return e;
-                if (!coins_copied[k]) {
-                    *what = "coins_copied";
-                    e = hipEventCreateWithFlags(&coins_copied[k], hipEventDisableTiming);
-                    if (e != hipSuccess) return e;
-                }
-            }
-            cap_coins = coins;
-        }
-        if (!h_count) {
-            *what = "h_count";
-            e = hipHostMalloc((void **)&h_count, sizeof(uint32_t) * 4);
-            if (e != hipSuccess) return e;
+            if (need_h0) PIPE_ALLOC(buf.h0, sizeof(float4) * qn);
+            PIPE_ALLOC(buf.energy, sizeof(float4) * want);
+            PIPE_ALLOC(buf.kd, sizeof(float4) * want);
+            PIPE_ALLOC(buf.ks, sizeof(float4) * want);
+            cap_paths = want;
+            have_h0 = need_h0;
         }
 #undef PIPE_ALLOC
         return hipSuccess;
+    failed:
+        // leave nothing half-allocated behind: the next call starts from scratch
+        free_paths();
+        for (void **p : counter_buffers()) { (void)hipFree(*p); *p = nullptr; }
+        return e;
     }
 
     // Adds the time of every recorded interval to host_stats and recycles the events.
@@ -1434,6 +935,7 @@ struct Pipeline {
                 float ms = 0.0f;
                 e = hipEventElapsedTime(&ms, events[i], events[i + 1]);
                 if (e != hipSuccess) break;
+                host_stats->trace_ms += ms;
                 if (kinds[i] == 0 || kinds[i] == 3) {
                     host_stats->extend_ms += ms;
                     host_stats->extend_launches++;
@@ -1466,49 +968,25 @@ struct Pipeline {
         return hipMemsetAsync(buf.wstats, 0, sizeof(unsigned long long) * WSTAT_SLOTS * PIPE_WAVES, stream);
     }
 
-    // Renders the `n` samples listed in d_samples and adds them to `sum`.
-    hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
-                   const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                   bool pool, bool in_place, int tail_div, int inplace_depths, bool share, bool share_closest, rt_stats *host_stats,
-                   const char **what);
+    // Renders the samples listed in `tab` and adds them to `sum`.  Enqueues kernels only (with `profiling`, events as
+    // well); the buffers must have been sized by ensure().
+    template <class CFG>
+    hipError_t launch_pass(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
+                           const PassTables &tab, hipStream_t stream, bool profiling, const PassForm &form, rt_stats *host_stats,
+                           const char **what);
+    hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum, const PassTables &tab,
+                   hipStream_t stream, bool profiling, const PassForm &form, rt_stats *host_stats, const char **what);
 };
 
-inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
-                                const uint32_t *d_samples, int n, hipStream_t stream, bool profiling, bool fused, bool refill,
-                                bool pool, bool in_place, int tail_div, int inplace_depths, bool share, bool share_closest, rt_stats *host_stats,
-                                const char **what) {
-    const bool use_bvh = bvh.enabled != 0;
-    // lane refill needs the hierarchy; it shades depth >= 1 in a kernel of its own
-    const bool use_refill = use_bvh && refill && fused;
-    // shared any-hit searches: with a node budget per round where traversals are long
-    const int share_mode = !(use_bvh && share) ? 0 : (sc.count >= SHARE_BUDGET_MIN_TRIANGLES ? 2 : 1);
+template <class CFG>
+inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
+                                        const PassTables &tab, hipStream_t stream, bool profiling, const PassForm &form,
+                                        rt_stats *host_stats, const char **what) {
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
     const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
     const uint32_t pps = tiles * 64u;
-    const size_t paths = (size_t)pps * (size_t)n;
-    if (paths > 0xFFFFFFF0ull) { *what = "batch has more than 2^32 paths"; return hipErrorInvalidValue; }
-    hipError_t e = ensure(paths, (size_t)n * max_depth, what);
-    if (e != hipSuccess) return e;
-    buf.region_cap = region_cap_for(paths);
-
-    // coin[slot][depth] = unitFloat(light_seed) < 0.5 after `depth` earlier draws (raytracer.glsl:553)
+    hipError_t e = hipSuccess;
 #define PIPE_TRY(expr) do { *what = #expr; e = (expr); if (e != hipSuccess) return e; } while (0)
-    const int cs = coin_slot;
-    coin_slot ^= 1;
-    PIPE_TRY(hipEventSynchronize(coins_copied[cs]));
-    uint32_t *coins = h_coins[cs];
-    for (int k = 0; k < n; k++) {
-        uint32_t ls = h_light_seeds[k];
-        for (int d = 0; d < max_depth; d++) {
-            const uint32_t state = ls * 747796405u + 2891336453u;
-            const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
-            ls = (word >> 22u) ^ word;
-            coins[(size_t)k * max_depth + d] = ((float)ls * (1.0f / 4294967296.0f) < 0.5f) ? 1u : 0u;
-        }
-    }
-    PIPE_TRY(hipMemcpyAsync(d_coins, coins, sizeof(uint32_t) * (size_t)n * max_depth, hipMemcpyHostToDevice, stream));
-    PIPE_TRY(hipEventRecord(coins_copied[cs], stream));
-
     if (profiling && ev_used > 8192) PIPE_TRY(collect_times(host_stats));
     auto stamp = [&](int kind_of_next_interval) -> hipError_t {
         if (!profiling) return hipSuccess;
@@ -1521,126 +999,62 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
         kinds.push_back(kind_of_next_interval);
         return hipEventRecord(events[ev_used++], stream);
     };
-
     const dim3 grid(PIPE_WAVES / WG_WAVES), block(64 * WG_WAVES);
-    int q_in = 0;
-    for (int depth = 0; depth < max_depth; depth++) {
-        PIPE_TRY(stamp(depth == 0 ? 3 : 0));
-#define LAUNCH_EXTEND(F, FU, BV)                                                                                        \
-    hipLaunchKernelGGL((k_extend<F, FU, BV>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples, d_coins, \
-                       pps, (uint32_t)n, max_depth)
-        if (fused && in_place && depth == 0) {
-            // depth 0 runs its probes in place (k_first), so q_in = 0 is never read and the next queue is 1
-            if (use_bvh && pool && buf.region_cap >= POOL_MIN_REGION)
-                hipLaunchKernelGGL(k_first_pool, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins, pps,
-                                   (uint32_t)n, max_depth);
-            else if (use_bvh && share_mode == 2) hipLaunchKernelGGL((k_first<true, 2>), grid, block, 0, stream, sc, bvh, light_bvh, fr,
-                                                                    buf, d_samples, d_coins, pps, (uint32_t)n, max_depth);
-            else if (use_bvh && share_mode == 1) hipLaunchKernelGGL((k_first<true, 1>), grid, block, 0, stream, sc, bvh, light_bvh, fr,
-                                                                    buf, d_samples, d_coins, pps, (uint32_t)n, max_depth);
-            else if (use_bvh) hipLaunchKernelGGL(k_first<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins,
-                                                 pps, (uint32_t)n, max_depth);
-            else hipLaunchKernelGGL(k_first<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, d_samples, d_coins,
-                                    pps, (uint32_t)n, max_depth);
-            PIPE_TRY(hipGetLastError());
-            PIPE_TRY(stamp(-1));
-            q_in ^= 1;
-            continue;
-        }
-        if (use_bvh && fused && depth > 0 && depth <= inplace_depths) {
-            // this bounce with its probes in place, as at depth 0
-#define LAUNCH_TAIL(ONE_, DEPTH_)                                                                                            \
-    do {                                                                                                                     \
-        if (share_mode == 2) hipLaunchKernelGGL((k_tail<ONE_, 2>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, DEPTH_, q_in, \
-                                                d_coins, pps, max_depth);                                                    \
-        else if (share_mode == 1) hipLaunchKernelGGL((k_tail<ONE_, 1>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, DEPTH_, \
-                                                     q_in, d_coins, pps, max_depth);                                         \
-        else hipLaunchKernelGGL((k_tail<ONE_, 0>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, DEPTH_, q_in, d_coins, pps,  \
-                                max_depth);                                                                                  \
-    } while (0)
-            LAUNCH_TAIL(true, depth);
-            PIPE_TRY(hipGetLastError());
-            PIPE_TRY(stamp(-1));
-            q_in ^= 1;
-            continue;
-        }
-        if (use_refill && depth > 0) {
-            hipLaunchKernelGGL(k_extend_refill, grid, block, 0, stream, sc, bvh, buf, q_in);
+    // depth 0 runs its probes in place (k_first): queue 0 is never read and the first queue is 1
+    PIPE_TRY(stamp(3));
+    hipLaunchKernelGGL(k_first<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
+    PIPE_TRY(hipGetLastError());
+    PIPE_TRY(stamp(-1));
+    int q_in = 1;
+    const int staged_end = form.staged_depths < 0 ? max_depth : (1 + form.staged_depths < max_depth ? 1 + form.staged_depths : max_depth);
+    for (int depth = 1; depth < staged_end; depth++) {
+        PIPE_TRY(stamp(0));
+        if (CFG::BVH && form.refill) {
+            hipLaunchKernelGGL(k_extend_refill<CFG>, grid, block, 0, stream, sc, bvh, buf, q_in);
             PIPE_TRY(hipGetLastError());
             PIPE_TRY(stamp(2));
-            hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins, pps,
-                               (uint32_t)n, max_depth);
-            PIPE_TRY(hipGetLastError());
-        } else if (fused) {
-            if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, true, true); else LAUNCH_EXTEND(true, true, false); }
-            else if (use_bvh && share_closest && share_mode == 2)
-                hipLaunchKernelGGL((k_extend<false, true, true, 2>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples,
-                                   d_coins, pps, (uint32_t)n, max_depth);
-            else if (use_bvh && share_closest && share_mode == 1)
-                hipLaunchKernelGGL((k_extend<false, true, true, 1>), grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, d_samples,
-                                   d_coins, pps, (uint32_t)n, max_depth);
-            else { if (use_bvh) LAUNCH_EXTEND(false, true, true); else LAUNCH_EXTEND(false, true, false); }
-            PIPE_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, sc, fr, buf, depth, q_in, tab, pps, max_depth);
         } else {
-            if (depth == 0) { if (use_bvh) LAUNCH_EXTEND(true, false, true); else LAUNCH_EXTEND(true, false, false); }
-            else { if (use_bvh) LAUNCH_EXTEND(false, false, true); else LAUNCH_EXTEND(false, false, false); }
-            PIPE_TRY(hipGetLastError());
-            PIPE_TRY(stamp(2));
-            if (depth == 0)
-                hipLaunchKernelGGL(k_shade<true>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins,
-                                   pps, (uint32_t)n, max_depth);
-            else
-                hipLaunchKernelGGL(k_shade<false>, grid, block, 0, stream, sc, fr, buf, depth, q_in, d_samples, d_coins,
-                                   pps, (uint32_t)n, max_depth);
-            PIPE_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_extend<CFG>, grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, tab, pps, max_depth);
         }
-#undef LAUNCH_EXTEND
+        PIPE_TRY(hipGetLastError());
         PIPE_TRY(stamp(1));
-        if (use_refill && !share) {      // shared any-hit searches beat refilled ones (1 M triangles: 8.3 vs 11.1 ms)
-            hipLaunchKernelGGL(k_probe_refill, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
-        } else if (use_bvh && share_mode == 2) {
-            hipLaunchKernelGGL((k_probe_shadow<true, 2>), grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
-            PIPE_TRY(hipGetLastError());
-            hipLaunchKernelGGL((k_probe_glossy<true, 2>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
-        } else if (use_bvh && share_mode == 1) {
-            hipLaunchKernelGGL((k_probe_shadow<true, 1>), grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
-            PIPE_TRY(hipGetLastError());
-            hipLaunchKernelGGL((k_probe_glossy<true, 1>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
-        } else if (use_bvh) {
-            hipLaunchKernelGGL(k_probe_shadow<true>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
-            PIPE_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_probe_glossy<true>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
-        } else {
-            hipLaunchKernelGGL(k_probe_shadow<false>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
-            PIPE_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_probe_glossy<false>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
-        }
+        hipLaunchKernelGGL(k_probe_shadow<CFG>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
+        PIPE_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_probe_glossy<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
         PIPE_TRY(hipGetLastError());
         PIPE_TRY(stamp(-1));
         q_in ^= 1;
-        // Deep paths are rare.  From depth 3 on the host looks at the size of the next extend queue: it stops when
-        // the queue is empty, and hands what is left to the tail kernel once that is a small fraction of the batch.
-        const bool use_tail = use_bvh && fused && tail_div > 0;
-        if (depth >= (use_tail ? RT_TAIL_FIRST_CHECK : 3) && depth + 1 < max_depth) {
-            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(256), 0, stream, buf.n_ext[q_in], PIPE_WAVES, buf.total);
-            PIPE_TRY(hipGetLastError());
-            PIPE_TRY(hipMemcpyAsync(h_count, buf.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            PIPE_TRY(hipStreamSynchronize(stream));
-            if (h_count[0] == 0) break;
-            if (use_tail && (size_t)h_count[0] * (size_t)tail_div <= paths) {
-                PIPE_TRY(stamp(0));
-                LAUNCH_TAIL(false, depth + 1);
-                PIPE_TRY(hipGetLastError());
-                PIPE_TRY(stamp(-1));
-                break;
-            }
-        }
+    }
+    if (staged_end < max_depth) {
+        PIPE_TRY(stamp(0));
+        hipLaunchKernelGGL(k_tail<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, staged_end, q_in, tab, pps, max_depth);
+        PIPE_TRY(hipGetLastError());
+        PIPE_TRY(stamp(-1));
     }
     hipLaunchKernelGGL(k_resolve, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
-                       fr.height, pps, (uint32_t)n);
+                       fr.height, pps, tab.n);
     PIPE_TRY(hipGetLastError());
 #undef PIPE_TRY
     return hipSuccess;
+}
+
+inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
+                                const PassTables &tab, hipStream_t stream, bool profiling, const PassForm &form,
+                                rt_stats *host_stats, const char **what) {
+    const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
+    const size_t paths = (size_t)tiles * 64u * (size_t)tab.n;
+    if (paths > 0xFFFFFFF0ull) { *what = "batch has more than 2^32 paths"; return hipErrorInvalidValue; }
+    if (paths > cap_paths || (form.bvh && form.refill && !have_h0)) { *what = "queues not sized for this pass"; return hipErrorInvalidValue; }
+    buf.region_cap = region_cap_for(cap_paths);
+#define RUN_AS(B, S, R) return launch_pass<KernelCfg<B, S, R>>(sc, bvh, light_bvh, fr, sum, tab, stream, profiling, form, host_stats, what)
+    if (!form.bvh) RUN_AS(false, 0, false);
+    if (form.resident) { if (form.share) RUN_AS(true, 1, true); RUN_AS(true, 0, true); }
+    if (!form.share) RUN_AS(true, 0, false);
+    // shared any-hit searches: with a node budget per round where traversals are long
+    if (sc.count >= SHARE_BUDGET_MIN_TRIANGLES) RUN_AS(true, 2, false);
+    RUN_AS(true, 1, false);
+#undef RUN_AS
 }
 
 }  // namespace rt

@@ -11,8 +11,10 @@
  *     gives the text of the last failure on that context.
  *   - A context is bound to one GPU and may be used from one host thread at a time.
  *   - Host pointers passed in are copied before the call returns; the caller keeps
- *     ownership.  rt_trace() is asynchronous on the context's stream;
- *     rt_read_sum(), rt_synchronize() and rt_get_stats() wait for it.
+ *     ownership.  rt_trace() only enqueues kernels on the context's stream (it reads
+ *     nothing back and copies nothing; the first call for a larger target or pass
+ *     also allocates the path queues, any later one can be captured in a HIP graph);
+ *     rt_read_sum(), rt_synchronize() and rt_get_stats() wait for the stream.
  *   - The three record types are byte-identical to the reference's SSBO layouts.
  */
 #ifndef GPURT_H
@@ -77,7 +79,8 @@ typedef struct rt_stats {
     uint64_t extend0_launches;
     /* hierarchy traversal (option "accel"): node visits and triangle tests actually executed */
     uint64_t bvh_extend_nodes, bvh_extend_tris, bvh_probe_nodes, bvh_probe_tris;
-    uint64_t depth1_paths;      /* camera paths that went on to a second bounce (staged form with fused depth 0; else 0) */
+    uint64_t depth1_paths;      /* camera paths that went on to a second bounce (staged form; else 0) */
+    uint64_t queue_bytes;       /* device memory the path queues of the staged form hold at present */
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -96,7 +99,7 @@ int rt_synchronize(rt_context *ctx);
 /* Scene::finalizeObjects -> createTrianglesBuffers (Scene.cpp:382-395, :343-346):
  * the three immutable SSBOs plus the COUNT (:362) and LIGHTS (:293) uniforms.
  * Triangles [0, lights) are the emissive ones.  Records are re-laid-out to SoA on
- * the device. */
+ * the device.  At most 2^28 - 1 triangles (RT_ERR_LIMIT beyond). */
 int rt_upload_scene(rt_context *ctx,
                     const rt_triangle_model *models, const rt_triangle_shading *shadings,
                     uint32_t count, uint32_t lights,
@@ -171,33 +174,22 @@ int rt_read_srgb8(rt_context *ctx, uint8_t *rgb);
 int rt_get_stats(rt_context *ctx, rt_stats *out);
 int rt_reset_stats(rt_context *ctx);
 
-/* Tuning knobs; unknown names return RT_ERR_INVALID.
+/* Tuning knobs; unknown names return RT_ERR_INVALID.  None of them changes a result.
  *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
  *                   1 = staged kernels over compacted ray queues (default)
- *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 256; about 320 bytes of
- *                   device memory per pixel and sample of a pass)
+ *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 128; the queues of a pass
+ *                   take about 290 bytes of device memory per pixel and sample, rt_stats.queue_bytes tells)
  *   "accel"         -1 = bounding-volume hierarchy for scenes of 64 triangles or more (default),
- *                   0 = the reference's loops over all triangles, 1 = hierarchy always; results are identical
- *   "fuse_shade"    1 = the closest-hit kernel also shades its paths (default), 0 = separate shade kernel
- *   "refill"        1 = traversal kernels hand finished lanes new rays (needs the hierarchy and fuse_shade = 1),
- *                   0 = every wave processes its queue in chunks of 64, -1 = by scene size (default: from 65536
- *                   triangles on); results are identical
- *   "tail"          n > 0: once at most 1/n of a pass's paths is still under way (looked at after the third
- *                   bounce and every later one), one kernel walks the rest of every such path instead of three
- *                   launches per further bounce (default 64; needs the hierarchy and fuse_shade = 1); 0 = never;
- *                   results are identical
+ *                   0 = the reference's loops over all triangles, 1 = hierarchy always
+ *   "resident"      -1 = a hierarchy that fits (about 480 triangles, depth under 16) is staged into LDS whole, leaf
+ *                   triangles included (default), 0 = only its first nodes are
+ *   "refill"        1 = the closest-hit kernels of the bounces after the first hand finished lanes new rays (needs
+ *                   the hierarchy), 0 = every wave processes its queue in chunks of 64, -1 = by scene size
+ *                   (default: from 65536 triangles on)
+ *   "staged_depths" n >= 0: the n bounces after the first run as staged kernels, then one kernel walks the rest of
+ *                   every path that is still under way (default 2); -1 = every bounce runs staged
  *   "share"         1 = the lanes of a wave share the any-hit searches of its light probes: an idle lane takes a
- *                   subtree off the stack of a busy one (default; needs the hierarchy), 0 = every lane searches
- *                   alone; results are identical
- *   "share_closest" 1 = the closest-hit searches of the bounces after the first are shared in the same way
- *                   (default 0: no gain measured); results are identical
- *   "inplace_depths" n: the n bounces after the first also run their light probes in place instead of through
- *                   the probe queues (default 0: 1 % slower when on); results are identical
- *   "first_in_place" 1 = depth 0 runs in one kernel and its light probes run in place (default, faster),
- *                   0 = depth 0 goes through the queues like the deeper bounces; results are identical
- *   "pool"          1 = at depth 0 the waves of a workgroup pool their light probes and draw dense packets from
- *                   the pool (needs the hierarchy and fuse_shade = 1), 0 = every lane runs its own probe
- *                   (default, faster); results are identical
+ *                   subtree off the stack of a busy one (default; needs the hierarchy), 0 = every lane searches alone
  *   "tonemap"       what rt_read_srgb8 applies: 0 = sRGB transfer (default), 1 = ACES film curve + sRGB transfer
  *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
 int rt_set_option(rt_context *ctx, const char *name, int64_t value);

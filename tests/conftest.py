@@ -82,3 +82,42 @@ def gpu_ctx():
     ctx = g.Context(0)
     yield ctx
     ctx.close()
+
+
+class HipRuntime:
+    """The few HIP runtime calls some GPU tests need (streams, events, graph capture), bound with ctypes to the runtime
+    library the HIP extension itself is linked against, so that the test and the extension share one runtime."""
+
+    NOT_READY = 600          # hipErrorNotReady
+
+    def __init__(self):
+        import ctypes
+        self.c = ctypes
+        self.lib = ctypes.CDLL("libamdhip64.so.7")
+        vp = ctypes.c_void_p
+        self.lib.hipStreamCreate.argtypes = [ctypes.POINTER(vp)]
+        self.lib.hipStreamDestroy.argtypes = [vp]
+        self.lib.hipStreamSynchronize.argtypes = [vp]
+        self.lib.hipEventCreate.argtypes = [ctypes.POINTER(vp)]
+        self.lib.hipEventRecord.argtypes = [vp, vp]
+        self.lib.hipEventQuery.argtypes = [vp]
+        self.lib.hipEventDestroy.argtypes = [vp]
+        self.lib.hipStreamBeginCapture.argtypes = [vp, ctypes.c_int]
+        self.lib.hipStreamEndCapture.argtypes = [vp, ctypes.POINTER(vp)]
+        self.lib.hipGraphInstantiate.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ctypes.c_size_t]
+        self.lib.hipGraphLaunch.argtypes = [vp, vp]
+        self.lib.hipGraphExecDestroy.argtypes = [vp]
+        self.lib.hipGraphDestroy.argtypes = [vp]
+
+    def check(self, rc):
+        assert rc == 0, "HIP call failed with code %d" % rc
+
+    def stream(self):
+        h = self.c.c_void_p()
+        self.check(self.lib.hipStreamCreate(self.c.byref(h)))
+        return h
+
+    def event(self):
+        h = self.c.c_void_p()
+        self.check(self.lib.hipEventCreate(self.c.byref(h)))
+        return h

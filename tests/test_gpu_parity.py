@@ -23,29 +23,26 @@ def _upload(ctx, scene, env):
     ctx.upload_env(env)
 
 
-def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM):
-    # pipeline 0 = single kernel, 1 = staged (default: hierarchy, fused shading), 2 = staged with a separate shade
-    # kernel at every depth, 3 = staged, loops over all triangles instead of the hierarchy, 4 = staged, hierarchy,
-    # traversal kernels with lane refill, 5 = staged, hierarchy, depth 0 with the workgroup's probe pool,
-    # 6 = staged, hierarchy, depth 0 through the queues like the deeper bounces, 7 = staged, hierarchy, no tail kernel
-    # (1 hands the last paths of a pass to the tail kernel as soon as at most 1/64 of them is left), 8 = the tail
-    # kernel takes whatever is left after the third bounce, 9 = the second and third bounce also run their probes in place,
-    # 10 = every lane runs its own any-hit search (1: the lanes of a wave share them), 11 = the closest-hit searches
-    # of the deeper bounces are shared as well
-    ctx.set_option("fuse_shade", 0 if pipeline == 2 else 1)
-    ctx.set_option("accel", 0 if pipeline == 3 else 1)
-    ctx.set_option("refill", 1 if pipeline == 4 else 0)
-    ctx.set_option("pool", 1 if pipeline == 5 else 0)
-    ctx.set_option("first_in_place", 0 if pipeline == 6 else 1)
-    ctx.set_option("tail", 0 if pipeline == 7 else (1 if pipeline == 8 else 64))
-    ctx.set_option("inplace_depths", 2 if pipeline == 9 else 0)
-    ctx.set_option("share", 0 if pipeline == 10 else 1)
-    ctx.set_option("share_closest", 1 if pipeline == 11 else 0)
-    pipeline = min(pipeline, 1)
-    ctx.set_option("pipeline", pipeline)
+# Forms of the same computation (`pipeline` argument of _render); every one must give the same bits.
+#   0 single kernel, loops over all triangles         1 staged, library defaults (hierarchy, resident in LDS when it fits,
+#   2 staged, every bounce staged (no tail kernel)      shared any-hit searches, two staged bounces then the tail kernel)
+#   3 staged, loops over all triangles                4 staged, closest-hit kernels with lane refill (1 turns it on by
+#                                                       itself from 65536 triangles on, the other forms keep it off)
+#   5 staged, tail kernel right after depth 0         6 staged, hierarchy never resident in LDS
+#   7 staged, every lane searches alone (no sharing)  8 staged, loops over all triangles, every bounce staged
+FORMS = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+
+
+def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM, exposure=1.0):
+    ctx.set_option("accel", 0 if pipeline in (3, 8) else 1)
+    ctx.set_option("refill", 1 if pipeline == 4 else (-1 if pipeline == 1 else 0))
+    ctx.set_option("staged_depths", -1 if pipeline in (2, 8) else (0 if pipeline == 5 else 2))
+    ctx.set_option("resident", 0 if pipeline == 6 else -1)
+    ctx.set_option("share", 0 if pipeline == 7 else 1)
+    ctx.set_option("pipeline", min(pipeline, 1))
     ctx.set_option("batch_samples", batch)
     ctx.resize(w, h)
-    ctx.set_frame(cam, clock, recursion, 1.0)
+    ctx.set_frame(cam, clock, recursion, exposure)
     ctx.trace(begin, count, stride)
     img, n = ctx.read_sum()
     assert n == count
@@ -124,12 +121,12 @@ def test_hierarchy_equals_index_order_loop(gpu_ctx, name):
 REF_IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close"]
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("pipeline", FORMS)
 @pytest.mark.parametrize("case", REF_IMAGE_CASES)
 def test_images_equal_reference_shader(gpu_ctx, case, pipeline):
     """Images the reference's main() wrote for single SAMPLE values, bit for bit.  The reference stores
     colour * 1/(SAMPLE+1) on a cleared target (raytracer.glsl:609-613); this library returns the colour."""
-    if pipeline in (0, 3) and case.startswith("obiwan"):
+    if pipeline in (0, 3, 8) and case.startswith("obiwan"):
         pytest.skip("loops over all 12030 triangles are covered by the smaller scenes")
     g = np.load(os.path.join(GOLDEN, "ref_image_%s.npz" % case))
     _upload(gpu_ctx, load_scene(str(g["scene"])), g["env"])
@@ -173,7 +170,7 @@ def test_mean_equals_reference_running_mean(gpu_ctx):
     assert np.allclose(total / 16.0, want, rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("pipeline", FORMS)
 def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
     _upload(gpu_ctx, cubes, constant_env())
     for spp in (1, 4, 16):
@@ -183,7 +180,7 @@ def test_golden_images_bit_exact(gpu_ctx, cubes, pipeline):
         assert [st["pixel_samples"], st["rays"], st["shadow_probes"], st["glossy_probes"]] == g["stats"].tolist()
 
 
-@pytest.mark.parametrize("pipeline", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("pipeline", FORMS)
 def test_image_vs_checker_gradient_env_ragged(gpu_ctx, oracle_mod, cubes, pipeline):
     # 52 x 37 is not a multiple of the 8 x 8 tile; the gradient environment exercises the bilinear lookup
     _upload(gpu_ctx, cubes, gradient_env())
@@ -228,7 +225,7 @@ def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
     sc.upload_env(gradient_env())
     cam = camera_matrix((0.0, 1.0, -2.0), (-0.3, 0.0))
     want, wst = sc.render(cam, DEFAULT_CLOCK, 16, 1.0, 32, 24, 0, 3)
-    for pipeline in (0, 1, 2, 3, 4, 7, 8, 9, 10, 11):
+    for pipeline in FORMS:
         img, st = _render(gpu_ctx, 32, 24, 0, 3, recursion=16, pipeline=pipeline, batch=2, cam=cam)
         assert np.array_equal(img, want, equal_nan=True), pipeline
         assert st["rays"] == wst["rays"] and st["glossy_probes"] == wst["glossy_probes"]
@@ -279,6 +276,67 @@ def test_call_sequences(oracle_mod, cubes, obiwan):
     finally:
         a.close()
         b.close()
+
+
+def test_trace_only_enqueues_and_can_be_captured(oracle_mod, cubes):
+    # rt_trace reads nothing back and copies nothing: (1) it returns while its kernels are still running, (2) once the
+    # queues have been sized by a first call, a call can be captured in a HIP graph and replayed
+    import ctypes
+    import gpuraytracer_amd as g
+    from conftest import HipRuntime
+    hip = HipRuntime()
+    ctx = g.Context(0)
+    stream = hip.stream()
+    try:
+        ctx.set_stream(stream.value)
+        ctx.upload_scene(*cubes)
+        ctx.upload_env(constant_env())
+        ctx.set_option("batch_samples", 32)
+        ctx.resize(1920, 1080)
+        ctx.set_frame(CAM, DEFAULT_CLOCK, 6, 1.0)
+        ctx.trace(0, 32, 1)                      # sizes the queues
+        ctx.synchronize()
+        done = hip.event()
+        ctx.trace(32, 96, 1)                     # three passes of 32 samples at 1080p: tens of milliseconds of device work
+        hip.check(hip.lib.hipEventRecord(done, stream))
+        assert hip.lib.hipEventQuery(done) == hip.NOT_READY, "rt_trace waited for the device"
+        ctx.synchronize()
+        assert hip.lib.hipEventQuery(done) == 0
+        hip.lib.hipEventDestroy(done)
+        # capture: 6 samples in passes of 4 + 2 on a small target, replayed twice
+        ctx.set_option("batch_samples", 4)
+        ctx.resize(64, 40)
+        ctx.trace(0, 6, 1)
+        want, _ = ctx.read_sum()
+        ctx.trace(0, 6, 1)                       # the same samples once more on top (what a second replay does)
+        want_twice, _ = ctx.read_sum()
+        sc = oracle_mod.OracleScene(*cubes)
+        sc.upload_env(constant_env())
+        ref, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 64, 40, 0, 6)
+        assert np.array_equal(want, ref)
+        ctx.resize(64, 40)                       # clears the sums
+        graph, graph_exec = ctypes.c_void_p(), ctypes.c_void_p()
+        hip.check(hip.lib.hipStreamBeginCapture(stream, 0))
+        try:
+            ctx.trace(0, 6, 1)
+        finally:
+            rc = hip.lib.hipStreamEndCapture(stream, ctypes.byref(graph))
+        hip.check(rc)
+        hip.check(hip.lib.hipGraphInstantiate(ctypes.byref(graph_exec), graph, None, None, 0))
+        # capturing executes nothing, so one replay renders the 6 samples once
+        hip.check(hip.lib.hipGraphLaunch(graph_exec, stream))
+        hip.check(hip.lib.hipStreamSynchronize(stream))
+        once = ctx.read_sum()[0]
+        assert np.array_equal(once, want)
+        hip.check(hip.lib.hipGraphLaunch(graph_exec, stream))
+        hip.check(hip.lib.hipStreamSynchronize(stream))
+        twice = ctx.read_sum()[0]
+        assert np.array_equal(twice, want_twice)
+        hip.lib.hipGraphExecDestroy(graph_exec)
+        hip.lib.hipGraphDestroy(graph)
+    finally:
+        ctx.close()
+        hip.lib.hipStreamDestroy(stream)
 
 
 @pytest.mark.parametrize("w,h,recursion,count", [(1, 1, 6, 3), (9, 3, 1, 2), (8, 8, 2, 1), (65, 7, 6, 70), (3, 130, 40, 2)])
@@ -343,7 +401,7 @@ def test_textured_materials_bit_exact(gpu_ctx, oracle_mod):
         target.set_has_texture(flags)
     clock, recursion = int(g["clock"]), int(g["recursion"])
     want, wst = sc.render(g["camera"], clock, recursion, 1.0, 48, 32, 0, 4)
-    for pipeline in (0, 1, 2, 3, 4):
+    for pipeline in (0, 1, 3, 4, 5, 6):
         img, st = _render(gpu_ctx, 48, 32, 0, 4, clock=clock, recursion=recursion, pipeline=pipeline, cam=g["camera"])
         assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
         assert st["rays"] == wst["rays"]
@@ -407,7 +465,7 @@ def test_random_soups(gpu_ctx, oracle_mod, tmp_path, seed):
     cam = camera_matrix((0.2, 0.4, -4.5), (-0.1, 0.05))
     want, wst = sc.render(cam, 1000 + seed, 8, 1.0, 72, 56, 0, 5)
     assert wst["rays"] > 1.05 * wst["pixel_samples"] and wst["shadow_probes"] > 500 and wst["glossy_probes"] > 500
-    for pipeline in (0, 1, 3, 4, 7, 10, 11):
+    for pipeline in (0, 1, 2, 3, 4, 5, 7):
         img, st = _render(gpu_ctx, 72, 56, 0, 5, recursion=8, clock=1000 + seed, pipeline=pipeline, batch=2, cam=cam)
         same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
         assert same.all(), (seed, pipeline, int((~same).sum()))
@@ -508,9 +566,131 @@ def test_synthetic_height_field_textured(gpu_ctx, oracle_mod, tmp_path):
                 target.upload_atlas_layer(m, k, layers[k])
         target.set_has_texture(flags)
     want, wst = sc.render(cam, 777, 6, 1.0, 64, 40, 0, 2)
-    for pipeline in (1, 3, 4):
+    for pipeline in (1, 3, 4, 5):
         img, st = _render(gpu_ctx, 64, 40, 0, 2, clock=777, pipeline=pipeline, cam=cam)
         assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
         assert st["rays"] == wst["rays"] and st["shadow_probes"] == wst["shadow_probes"]
     assert wst["rays"] > 1.05 * wst["pixel_samples"] and wst["shadow_probes"] > 0     # the camera sees the surface
     gpu_ctx.set_atlas_size(4096)
+
+
+@pytest.fixture(scope="module")
+def million_triangles(tmp_path_factory):
+    from gpuraytracer_amd import host, synthetic
+    base = str(tmp_path_factory.mktemp("c3") / "grid")
+    n = synthetic.write_displaced_grid(base, 724)
+    scene = host.load_wavefront(base)
+    assert len(scene[0]) == n == 1048358 and scene[2] == 4
+    return scene
+
+
+def test_million_triangles_hierarchy_equals_loop(gpu_ctx, million_triangles):
+    # What scenes of 65 536 triangles or more take and smaller ones do not: leaves of at most two triangles, lane
+    # refill switched on by itself, any-hit searches with a node budget per round, a hierarchy deeper than 20.
+    models = million_triangles[0]
+    _upload(gpu_ctx, million_triangles, gradient_env())
+    rng = np.random.default_rng(3)
+    n = 120000
+    o = np.empty((n, 3)); d = np.empty((n, 3))
+    k = n // 3
+    # a third from where the measurement's camera stands, a third from anywhere, a third aimed exactly at vertices and
+    # edge midpoints of the height field (several triangles tie in depth there)
+    o[:k] = np.array([0.0, 2.2, -5.5]) + rng.normal(0, 0.05, (k, 3))
+    d[:k] = rng.normal(0, 1, (k, 3)) * [0.6, 0.35, 0.2] + [0.0, -0.45, 0.9]
+    o[k:] = rng.uniform([-5, -1, -5], [5, 4, 5], (n - k, 3))
+    d[k:2 * k] = rng.normal(0, 1, (k, 3))
+    tri = rng.integers(0, len(models), n - 2 * k)
+    a = models["position"][tri].astype(np.float64)
+    b = a + models["u"][tri]
+    target = np.where(rng.integers(0, 2, n - 2 * k)[:, None] == 0, a, 0.5 * (a + b))
+    d[2 * k:] = target - o[2 * k:]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o32, d32 = o.astype(np.float32), d.astype(np.float32)
+    gpu_ctx.set_option("accel", 0)
+    ids0, uvt0 = gpu_ctx.closest_hit_batch(o32, d32)
+    gpu_ctx.set_option("accel", 1)
+    ids1, uvt1 = gpu_ctx.closest_hit_batch(o32, d32)
+    assert np.array_equal(ids0, ids1), int((ids0 != ids1).sum())
+    assert np.array_equal(uvt0.view(np.uint32), uvt1.view(np.uint32))
+    assert (ids0 >= 0).mean() > 0.5 and len(np.unique(ids0)) > 20000
+    # whole paths: the loop form is the reference's algorithm; the staged forms must give its bits
+    cam = camera_matrix((0.0, 2.2, -5.5), (-0.45, 0.0))
+    want, wst = _render(gpu_ctx, 64, 40, 0, 2, clock=4711, pipeline=3, batch=2, cam=cam)
+    assert wst["rays"] > 1.1 * wst["pixel_samples"] and wst["shadow_probes"] > 300 and wst["glossy_probes"] > 300
+    for pipeline in (1, 2, 4, 5, 7):
+        img, st = _render(gpu_ctx, 64, 40, 0, 2, clock=4711, pipeline=pipeline, batch=2, cam=cam)
+        same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
+        assert same.all(), (pipeline, int((~same).sum()))
+        for key in ("rays", "shadow_probes", "glossy_probes"):
+            assert st[key] == wst[key], (pipeline, key)
+
+
+def _read_exr_uncompressed(path):
+    """OpenEXR scanline file without compression, FLOAT channels, read with nothing but struct: returns
+    ({channel name: [h, w] float32}, channel names in file order, header attributes)."""
+    import struct
+    data = open(path, "rb").read()
+    magic, version = struct.unpack_from("<II", data, 0)
+    assert magic == 20000630 and version == 2
+    pos, attrs = 8, {}
+
+    def cstr(at):
+        end = data.index(b"\0", at)
+        return data[at:end].decode(), end + 1
+    while data[pos] != 0:
+        name, pos = cstr(pos)
+        kind, pos = cstr(pos)
+        size = struct.unpack_from("<I", data, pos)[0]
+        attrs[name] = (kind, data[pos + 4:pos + 4 + size])
+        pos += 4 + size
+    pos += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    xmin, ymin, xmax, ymax = struct.unpack("<iiii", attrs["dataWindow"][1])
+    w, h = xmax - xmin + 1, ymax - ymin + 1
+    names, cl, at = [], attrs["channels"][1], 0
+    while cl[at] != 0:
+        end = cl.index(b"\0", at)
+        names.append(cl[at:end].decode())
+        ptype, _, xs, ys = struct.unpack_from("<IIii", cl, end + 1)
+        assert ptype == 2 and xs == 1 and ys == 1              # FLOAT, no subsampling
+        at = end + 1 + 16
+    offsets = struct.unpack_from("<%dQ" % h, data, pos)
+    planes = {nm: np.empty((h, w), np.float32) for nm in names}
+    for row, off in enumerate(offsets):
+        y, size = struct.unpack_from("<iI", data, off)
+        assert y == ymin + row and size == 4 * w * len(names)
+        for k, nm in enumerate(names):
+            planes[nm][row] = np.frombuffer(data, "<f4", w, off + 8 + 4 * w * k)
+    return planes, names, attrs
+
+
+def test_host_program_renders_and_writes_exr(oracle_mod, tmp_path):
+    # The C++ host (csrc/host/: Scene with the reference's method names + the gpuPT main, the counterpart of
+    # RayTracer.cpp's finalRender) end to end on the GPU: OBJ/MTL ingest, upload, 4 samples, mean image to OpenEXR.
+    # The file is parsed here independently of the library's own reader; rows are bottom-up as Scene::exportEXR
+    # leaves them (Scene.cpp:496-509), channels alphabetical (B, G, R).
+    import subprocess
+    from conftest import ROOT
+    from gpuraytracer_amd import host
+    base = str(tmp_path / "soup")
+    _write_soup(base, 7, 500)
+    out = str(tmp_path / "final.exr")
+    exe = os.path.join(ROOT, "gpuraytracer_amd", "gpuPT")
+    assert os.path.exists(exe), "build gpuPT with __graft_entry__.build()"
+    res = subprocess.run([exe, base, "64", "48", "4", out], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "Scene Loaded" in res.stdout and "samples/s" in res.stdout
+    planes, names, attrs = _read_exr_uncompressed(out)
+    assert names == ["B", "G", "R"]
+    scene = host.load_wavefront(base)
+    sc = oracle_mod.OracleScene(*scene)
+    sc.upload_env(constant_env())
+    want, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 64, 48, 0, 4)          # the program's camera, clock and RECURSION
+    mean = want * (np.float32(1.0) / np.float32(4.0))
+    got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
+    same = (got.view(np.uint32) == mean.view(np.uint32)) | (np.isnan(got) & np.isnan(mean))
+    assert same.all(), int((~same).sum())
+    assert np.abs(got[0] - got[-1]).max() > 0                              # row 0 is TEXEL.y 0: the image is not symmetric
+    # and the library's own reader agrees with the independent one
+    back = host.read_exr(out)
+    assert np.array_equal(back[..., :3].view(np.uint32), got.view(np.uint32))
