@@ -15,7 +15,7 @@ MATERIAL_DTYPE = np.dtype([("albedo", "<f4", 4), ("specular_roughness", "<f4", 4
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_synchronize", "rt_upload_scene",
     "rt_set_atlas_size", "rt_upload_atlas_layer", "rt_set_has_texture", "rt_upload_env", "rt_prefilter_irradiance", "rt_resize",
-    "rt_set_sum_buffer", "rt_set_frame", "rt_trace", "rt_read_sum", "rt_closest_hit_batch",
+    "rt_set_sum_buffer", "rt_set_frame", "rt_trace", "rt_read_sum", "rt_read_sum_static", "rt_closest_hit_batch",
     "rt_closest_hit_batch_device", "rt_read_srgb8", "rt_get_stats", "rt_reset_stats", "rt_set_option",
 ]
 
@@ -73,6 +73,7 @@ def load_library():
     lib.rt_set_frame.argtypes = [vp, vp, c.c_uint32, c.c_int32, c.c_float]
     lib.rt_trace.argtypes = [vp, c.c_uint32, c.c_uint32, c.c_uint32]
     lib.rt_read_sum.argtypes = [vp, vp, c.POINTER(c.c_uint64)]
+    lib.rt_read_sum_static.argtypes = [vp, vp, c.POINTER(c.c_uint64)]
     lib.rt_closest_hit_batch.argtypes = [vp, vp, vp, c.c_uint64, vp, vp]
     lib.rt_closest_hit_batch_device.argtypes = [vp, vp, vp, c.c_uint64, vp, vp]
     lib.rt_read_srgb8.argtypes = [vp, vp]
@@ -187,6 +188,13 @@ class Context:
         rgb = np.empty((self.height, self.width, 3), dtype=np.float32)
         n = ctypes.c_uint64()
         self._check(self.lib.rt_read_sum(self.h, _ptr(rgb), ctypes.byref(n)))
+        return rgb, int(n.value)
+
+    def read_sum_static(self):
+        """read_sum through the library's built-in staging buffer (no device allocation)."""
+        rgb = np.empty((self.height, self.width, 3), dtype=np.float32)
+        n = ctypes.c_uint64()
+        self._check(self.lib.rt_read_sum_static(self.h, _ptr(rgb), ctypes.byref(n)))
         return rgb, int(n.value)
 
     def read_srgb8(self):

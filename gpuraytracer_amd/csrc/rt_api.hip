@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -251,6 +252,28 @@ __global__ void k_sum_to_rgb(const float4 *__restrict__ sum, unsigned long long 
     rgb[i * 3 + 2] = s.z;
 }
 
+// ---- staging buffer of rt_read_sum_static: device memory that belongs to the loaded code object, so the entry point
+// never allocates.  32 MiB = 2 796 202 pixels of three floats.  Each GPU the library runs on holds its own copy of the
+// array at its own address until the process ends; in host code the array's name is only a handle for
+// hipGetSymbolAddress, the address that call returns (per device) is what kernels and copies are given.
+constexpr size_t STATIC_FLOATS = (size_t)8 << 20;
+constexpr uint64_t STATIC_MAX_PIXELS = STATIC_FLOATS / 3;
+static __device__ __align__(256) float scratch[STATIC_FLOATS];
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+float *g_scratch_ptr[MAX_DEVICES] = {};       // device address of `scratch` on each GPU, looked up once per device
+
+// Looks up this device's address of `scratch` (the device must be current).  Called from rt_create.
+void lookup_scratch(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return;
+    float *ptr = nullptr;
+    if (hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)) == hipSuccess) g_scratch_ptr[device] = ptr;
+    else (void)hipGetLastError();             // rt_read_sum_static reports the missing buffer; everything else works
+}
+
 }  // namespace
 
 extern "C" {
@@ -273,6 +296,7 @@ int rt_create(int device, rt_context **out) {
         return RT_ERR_DEVICE;
     }
     ctx->stream = ctx->own_stream;
+    lookup_scratch(device);
     *out = ctx;
     return RT_OK;
 }
@@ -613,6 +637,35 @@ int rt_read_sum(rt_context *ctx, float *rgb, uint64_t *n_samples) {
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(d_rgb);
         if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "rt_read_sum: %s", hipGetErrorString(e));
+    } else {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n_samples) *n_samples = ctx->n_samples;
+    return RT_OK;
+}
+
+int rt_read_sum_static(rt_context *ctx, float *rgb, uint64_t *n_samples) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (ctx->width == 0 || !ctx->d_sum) return fail(ctx, RT_ERR_STATE, "rt_read_sum_static: no target");
+    const unsigned long long n = (unsigned long long)ctx->width * ctx->height;
+    if (n > STATIC_MAX_PIXELS)
+        return fail(ctx, RT_ERR_LIMIT, "rt_read_sum_static: %ux%u = %llu pixels, the built-in buffer holds %llu (use rt_read_sum)",
+                    ctx->width, ctx->height, n, (unsigned long long)STATIC_MAX_PIXELS);
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    float *staging = nullptr;
+    if (ctx->device < MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        staging = g_scratch_ptr[ctx->device];
+    }
+    if (!staging) return fail(ctx, RT_ERR_DEVICE, "rt_read_sum_static: the built-in buffer of device %d could not be located", ctx->device);
+    if (rgb) {
+        // every word that is copied out below is written by this launch first, so nothing of the previous call's
+        // contents has to be cleared
+        hipLaunchKernelGGL(k_sum_to_rgb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_sum, n, staging);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(rgb, staging, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "rt_read_sum_static: %s", hipGetErrorString(e));
     } else {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }

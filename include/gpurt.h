@@ -156,6 +156,14 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count,
  * and the number of samples summed per pixel. */
 int rt_read_sum(rt_context *ctx, float *rgb, uint64_t *n_samples);
 
+/* No counterpart in the reference.  rt_read_sum for callers that cannot allocate device memory (a preview loop that reads
+ * the image back after every pass, code under HIP graph capture, harnesses that forbid hipMalloc): the float3 staging
+ * image that rt_read_sum allocates and frees on every call lives in a 32 MiB array built into the library instead,
+ * so this call allocates nothing.  Same output as rt_read_sum, bit for bit.  Targets of more than 2 796 202 pixels
+ * (1920 x 1080 fits, 3840 x 2160 does not) return RT_ERR_LIMIT.  Every context on one GPU shares that GPU's array:
+ * calls on the same GPU must not overlap in time (two host threads, two streams), or they overwrite each other's image. */
+int rt_read_sum_static(rt_context *ctx, float *rgb, uint64_t *n_samples);
+
 /* No counterpart in the reference (findIntersection, raytracer.glsl:217-235, cannot be
  * called on its own there): closest hit for a batch of rays.  o_xyz/d_xyz are n*3
  * floats, id gets the triangle index (-1 = miss), uvt gets n*3 floats (u, v, t). */
