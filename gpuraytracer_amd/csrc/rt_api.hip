@@ -148,8 +148,8 @@ bool use_accel(const rt_context *ctx) {
 // Do both hierarchies fit the LDS of a workgroup (KernelCfg::RES)?
 bool fits_lds(const rt_context *ctx) {
     const rt_context::DevBvh &a = ctx->bvh, &l = ctx->light_bvh;
-    const int records = a.n_nodes + a.n_slots + (l.ok ? l.n_nodes + l.n_slots : 0);
-    return records <= RES_RECORDS && a.depth < RES_STACK && (!l.ok || l.depth < RES_STACK);
+    const int bytes = RES_NODE_BYTES * (a.n_nodes + (l.ok ? l.n_nodes : 0)) + 64 * (a.n_slots + (l.ok ? l.n_slots : 0));
+    return bytes <= RES_BYTES && a.depth < RES_STACK && (!l.ok || l.depth < RES_STACK);
 }
 
 void free_bvh(rt_context::DevBvh &b) {

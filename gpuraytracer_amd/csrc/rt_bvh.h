@@ -64,6 +64,9 @@ constexpr int BVH_LIGHT_TOP_NODES = 64;              // the same for the hierarc
 // (several hundred), which matters because the traversal kernels are bound by the latency of their dependent
 // accesses as much as by instruction issue (measured: 2 / 3 / 4 waves per SIMD take 18.3 / 14.2 / 12.6 ms).
 typedef const __attribute__((address_space(3))) v4f *lds_v4f_ptr;
+typedef const __attribute__((address_space(3))) char *lds_byte_ptr;
+typedef const __attribute__((address_space(3))) float *lds_f32_ptr;
+typedef const __attribute__((address_space(3))) int *lds_i32_ptr;
 template <bool RES_>
 struct BvhScratchT {
     static constexpr bool RES = RES_;
@@ -81,6 +84,33 @@ RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top, int max_nodes = BVH_TOP_NODES
     __syncthreads();
     return n_top;
 }
+// Node layout of a resident hierarchy (80 bytes, 20 words), made for slab tests without min/max.  Which plane of a
+// box a ray meets first along an axis follows from the sign of its direction alone, so a lane can fetch "near" and
+// "far" straight away if it may pick the address: per axis and child the words (lo, hi, lo) are stored, and a lane
+// reads two consecutive words from offset 0 (direction >= 0: lo then hi) or from offset 1 (hi then lo).
+//   words 0..5   x: lo0 hi0 lo0 lo1 hi1 lo1      words 6..11  y, 12..17 z likewise
+//   words 18,19  child links: inner node = byte offset of its record, leaf = the (negative) leaf code as it is
+// That takes the 12 min/max of a node step away (they issue at half the rate of multiply-adds on this chip).
+constexpr int RES_NODE_BYTES = 80;
+RT_DEV void bvh_stage_nodes_resident(const DBvh &bv, float *dst) {
+    const int n = bv.enabled ? bv.n_nodes * 20 : 0;
+    const float *src = (const float *)bv.nodes;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int node = i / 20, k = i - node * 20;
+        const float *s = src + 16 * node;        // (lo0.xyz, hi0.xyz, lo1.xyz, hi1.xyz, link0, link1, -, -)
+        float v;
+        if (k < 18) {
+            const int axis = k / 6, j = k - axis * 6;
+            const int child = j / 3, which = (j - child * 3) == 1;      // 1 = hi
+            v = s[6 * child + 3 * which + axis];
+        } else {
+            const int link = __float_as_int(s[12 + (k - 18)]);
+            v = __int_as_float(link >= 0 ? link * RES_NODE_BYTES : link);
+        }
+        dst[i] = v;
+    }
+    __syncthreads();
+}
 // The same for the leaf records of a resident hierarchy.
 RT_DEV void bvh_stage_leaves(const DBvh &bv, v4f *leaves) {
     const int n = bv.enabled ? bv.n_slots * 4 : 0;
@@ -89,11 +119,16 @@ RT_DEV void bvh_stage_leaves(const DBvh &bv, v4f *leaves) {
 }
 
 struct BvhRay {
-    f3 oi_lo, oi_hi;   // (origin -r) * inv and (origin + r) * inv: lo*inv - oi_hi and hi*inv - oi_lo widen the box by r
+    // plain form:    ca = (origin - r) * inv, cb = (origin + r) * inv: lo*inv - cb and hi*inv - ca widen the box by r
+    // resident form: ca = the constant of the plane met first, cb = of the plane met last (the two above, swapped where
+    //                the direction is negative); off = byte offsets into a node record that select (near, far) per axis
+    f3 ca, cb;
     f3 inv;
+    int off_x, off_y, off_z;
     bool finite;
 };
 
+template <bool RES>
 RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
     BvhRay b;
     const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y)),
@@ -101,11 +136,29 @@ RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
     const float r = m * (1.0f / 65536.0f) + 1e-30f;
     // reciprocal to 1 ulp: the slab test is conservative by far more than that
     b.inv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
-    b.oi_lo = mk3((ray.o.x - r) * b.inv.x, (ray.o.y - r) * b.inv.y, (ray.o.z - r) * b.inv.z);
-    b.oi_hi = mk3((ray.o.x + r) * b.inv.x, (ray.o.y + r) * b.inv.y, (ray.o.z + r) * b.inv.z);
+    if (RES) {
+        // r with the sign of the direction: the plane met first is lo for a positive direction (constant origin + r), hi
+        // for a negative one (constant origin - r)
+        const float rx = __builtin_copysignf(r, b.inv.x), ry = __builtin_copysignf(r, b.inv.y), rz = __builtin_copysignf(r, b.inv.z);
+        b.ca = mk3((ray.o.x + rx) * b.inv.x, (ray.o.y + ry) * b.inv.y, (ray.o.z + rz) * b.inv.z);
+        b.cb = mk3((ray.o.x - rx) * b.inv.x, (ray.o.y - ry) * b.inv.y, (ray.o.z - rz) * b.inv.z);
+        b.off_x = (int)((__float_as_uint(b.inv.x) >> 29) & 4u);
+        b.off_y = (int)((__float_as_uint(b.inv.y) >> 29) & 4u) + 24;
+        b.off_z = (int)((__float_as_uint(b.inv.z) >> 29) & 4u) + 48;
+    } else {
+        b.ca = mk3((ray.o.x - r) * b.inv.x, (ray.o.y - r) * b.inv.y, (ray.o.z - r) * b.inv.z);
+        b.cb = mk3((ray.o.x + r) * b.inv.x, (ray.o.y + r) * b.inv.y, (ray.o.z + r) * b.inv.z);
+        b.off_x = b.off_y = b.off_z = 0;
+    }
     const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
     b.finite = (s - s) == 0.0f;      // false when any component is NaN or infinite
     return b;
+}
+// The address offsets of the resident form again, from the reciprocal direction (cheaper than carrying them to another lane).
+RT_DEV void bvh_ray_offsets(BvhRay &b) {
+    b.off_x = (int)((__float_as_uint(b.inv.x) >> 29) & 4u);
+    b.off_y = (int)((__float_as_uint(b.inv.y) >> 29) & 4u) + 24;
+    b.off_z = (int)((__float_as_uint(b.inv.z) >> 29) & 4u) + 48;
 }
 
 // Slab test against a box widened by r (one fused multiply-add per plane; this test only has to be
@@ -114,9 +167,9 @@ RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
 // (inf - inf for a ray parallel to a slab), which errs on the side of visiting.  The rounding of these
 // operations (a few 2^-24 of |origin| * |inv|) is below 1/16 of the widening r * |inv| = 2^-16 * |origin| * |inv|.
 RT_DEV void box_slabs(const BvhRay &br, f3 lo, f3 hi, float t_max, float &t_in, float &t_out) {
-    const float ax = __builtin_fmaf(lo.x, br.inv.x, -br.oi_hi.x), bx = __builtin_fmaf(hi.x, br.inv.x, -br.oi_lo.x);
-    const float ay = __builtin_fmaf(lo.y, br.inv.y, -br.oi_hi.y), by = __builtin_fmaf(hi.y, br.inv.y, -br.oi_lo.y);
-    const float az = __builtin_fmaf(lo.z, br.inv.z, -br.oi_hi.z), bz = __builtin_fmaf(hi.z, br.inv.z, -br.oi_lo.z);
+    const float ax = __builtin_fmaf(lo.x, br.inv.x, -br.cb.x), bx = __builtin_fmaf(hi.x, br.inv.x, -br.ca.x);
+    const float ay = __builtin_fmaf(lo.y, br.inv.y, -br.cb.y), by = __builtin_fmaf(hi.y, br.inv.y, -br.ca.y);
+    const float az = __builtin_fmaf(lo.z, br.inv.z, -br.cb.z), bz = __builtin_fmaf(hi.z, br.inv.z, -br.ca.z);
     t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
                            __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
     t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
@@ -164,19 +217,39 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
         // a divergent loop: lanes leave as they reach a leaf or finish, and the wave goes on when none is left
         int budget = node_budget;
         while (run && node >= 0 && (!BUDGETED || budget-- > 0)) {
-            v4f q0, q1, q2, q3;
-            if (WS::RES || node < ws.n_top) {
-                q0 = ws.top[4 * node + 0]; q1 = ws.top[4 * node + 1]; q2 = ws.top[4 * node + 2]; q3 = ws.top[4 * node + 3];
-            } else {
-                const v4f *g = (const v4f *)bv.nodes;
-                q0 = g[4 * node + 0]; q1 = g[4 * node + 1]; q2 = g[4 * node + 2]; q3 = g[4 * node + 3];
-            }
+            float in0, out0, in1, out1;
+            int c0, c1;
             cnt.nodes += bvh_count_step();
             const float lim = t_limit();
-            float in0, out0, in1, out1;
-            box_slabs(br, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), lim, in0, out0);
-            box_slabs(br, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), lim, in1, out1);
-            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (WS::RES) {
+                // `node` is the byte offset of the record; (near, far) per axis and child through the lane's own offsets
+                const lds_byte_ptr rec = (lds_byte_ptr)ws.top + node;
+                const lds_f32_ptr px = (lds_f32_ptr)(rec + br.off_x), py = (lds_f32_ptr)(rec + br.off_y), pz = (lds_f32_ptr)(rec + br.off_z);
+                const lds_i32_ptr links = (lds_i32_ptr)(rec + 72);
+                const float n0x = px[0], f0x = px[1], n1x = px[3], f1x = px[4];
+                const float n0y = py[0], f0y = py[1], n1y = py[3], f1y = py[4];
+                const float n0z = pz[0], f0z = pz[1], n1z = pz[3], f1z = pz[4];
+                c0 = links[0]; c1 = links[1];
+                in0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(n0x, br.inv.x, -br.ca.x), __builtin_fmaf(n0y, br.inv.y, -br.ca.y)),
+                                                      __builtin_fmaf(n0z, br.inv.z, -br.ca.z)), 0.0f);
+                out0 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(f0x, br.inv.x, -br.cb.x), __builtin_fmaf(f0y, br.inv.y, -br.cb.y)),
+                                                       __builtin_fmaf(f0z, br.inv.z, -br.cb.z)), lim);
+                in1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(n1x, br.inv.x, -br.ca.x), __builtin_fmaf(n1y, br.inv.y, -br.ca.y)),
+                                                      __builtin_fmaf(n1z, br.inv.z, -br.ca.z)), 0.0f);
+                out1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(f1x, br.inv.x, -br.cb.x), __builtin_fmaf(f1y, br.inv.y, -br.cb.y)),
+                                                       __builtin_fmaf(f1z, br.inv.z, -br.cb.z)), lim);
+            } else {
+                v4f q0, q1, q2, q3;
+                if (node < ws.n_top) {
+                    q0 = ws.top[4 * node + 0]; q1 = ws.top[4 * node + 1]; q2 = ws.top[4 * node + 2]; q3 = ws.top[4 * node + 3];
+                } else {
+                    const v4f *g = (const v4f *)bv.nodes;
+                    q0 = g[4 * node + 0]; q1 = g[4 * node + 1]; q2 = g[4 * node + 2]; q3 = g[4 * node + 3];
+                }
+                box_slabs(br, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), lim, in0, out0);
+                box_slabs(br, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), lim, in1, out1);
+                c0 = __float_as_int(q3.x); c1 = __float_as_int(q3.y);
+            }
             // the decisions as wave masks: their combinations then cost scalar instructions, and each
             // per-lane choice a single select
             const unsigned long long m0 = __builtin_amdgcn_ballot_w64(in0 <= out0);
@@ -310,7 +383,7 @@ RT_DEV void closest_fold_redo(const DScene &sc, const Ray &ray, bool redo, int b
 template <class WS>
 RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, int begin_id, int end_id,
                            int current, float w_init, const WS &ws, f4 &isec, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
     ClosestFold cf;
     closest_fold_reset(cf, w_init);
     auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, begin_id, end_id, current, cf); return true; };
@@ -346,7 +419,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
     lds_u8_ptr flags = scratch, table = scratch + 64;
     flags[lane] = 0;
     int owner = lane;
-    BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
     TravState ts;
     ts.node = 0; ts.sp = 0; ts.run = active;
     auto leaf = [&](int slot) -> bool {
@@ -379,12 +452,13 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
             r2.o = mk3(lane_read(ray.o.x, from4), lane_read(ray.o.y, from4), lane_read(ray.o.z, from4));
             r2.d = mk3(lane_read(ray.d.x, from4), lane_read(ray.d.y, from4), lane_read(ray.d.z, from4));
             b2.inv = mk3(lane_read(br.inv.x, from4), lane_read(br.inv.y, from4), lane_read(br.inv.z, from4));
-            b2.oi_lo = mk3(lane_read(br.oi_lo.x, from4), lane_read(br.oi_lo.y, from4), lane_read(br.oi_lo.z, from4));
-            b2.oi_hi = mk3(lane_read(br.oi_hi.x, from4), lane_read(br.oi_hi.y, from4), lane_read(br.oi_hi.z, from4));
+            b2.ca = mk3(lane_read(br.ca.x, from4), lane_read(br.ca.y, from4), lane_read(br.ca.z, from4));
+            b2.cb = mk3(lane_read(br.cb.x, from4), lane_read(br.cb.y, from4), lane_read(br.cb.z, from4));
             e2 = mk3(lane_read(extra.x, from4), lane_read(extra.y, from4), lane_read(extra.z, from4));
             const float l2 = lane_read(lim, from4);
             if (takes) {
-                ray = r2; br.inv = b2.inv; br.oi_lo = b2.oi_lo; br.oi_hi = b2.oi_hi; extra = e2; lim = l2;
+                ray = r2; br.inv = b2.inv; br.ca = b2.ca; br.cb = b2.cb; extra = e2; lim = l2;
+                if (WS::RES) bvh_ray_offsets(br);
                 owner = t_owner;
                 ts.node = t_node; ts.sp = 0; ts.run = true;
             }
@@ -399,7 +473,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
 template <class WS>
 RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
                                const WS &ws, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
     const bool ok = br.finite && ((max_t - max_t) == 0.0f);
     bool blocked = false;
     auto leaf = [&](int slot) -> bool {
@@ -423,7 +497,7 @@ RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
 template <class WS>
 RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, const f4 &isec, int current, bool active,
                                const WS &ws, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
     const bool bounded = isec.z >= 0.0f;                 // a light was hit: only triangles not farther than it matter
     const float t_light = isec.z / isec.w;
     const bool ok = br.finite && (!bounded || (t_light - t_light) == 0.0f);

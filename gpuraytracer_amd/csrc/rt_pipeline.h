@@ -82,7 +82,7 @@ RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
 #define RT_MIN_WAVES 4                               // waves per SIMD the traversal kernels are compiled for (register budget)
 #endif
 constexpr int RES_STACK = RT_RES_STACK;              // traversal stack entries of the resident form (hierarchy depth < RES_STACK)
-constexpr int RES_RECORDS = 736;                     // 64-byte records (nodes + leaf slots of both hierarchies) that fit: 46 KB
+constexpr int RES_BYTES = 46 * 1024;                 // room for the resident records: 80 bytes per node, 64 per leaf slot, both hierarchies
 template <bool BVH_, int SHARE_, bool RES_>
 struct KernelCfg {
     static constexpr bool BVH = BVH_;
@@ -95,7 +95,7 @@ struct KernelCfg {
     // last 16 node slots of the second are the waves' 128-byte exchange areas) or the resident scene and 1 KB of
     // exchange areas.  80 KB at most: two workgroups per CU.
     static constexpr int STACK_INTS = BVH_ ? STACK * 64 * WG_WAVES : 64;
-    static constexpr int SCENE_V4F = !BVH_ ? 1 : (RES_ ? RES_RECORDS * 4 : (BVH_TOP_NODES + BVH_LIGHT_TOP_NODES) * 4);
+    static constexpr int SCENE_V4F = !BVH_ ? 1 : (RES_ ? RES_BYTES / 16 : (BVH_TOP_NODES + BVH_LIGHT_TOP_NODES) * 4);
     static constexpr int SHARE_BYTES = (BVH_ && RES_) ? 128 * WG_WAVES : 1;
 };
 
@@ -113,15 +113,18 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
     share = (lds_u8_ptr)share_mem;
     if (!CFG::BVH) return;
     if (CFG::RES) {
-        v4f *nodes = scene_mem, *leaves = nodes + 4 * bv.n_nodes;
-        v4f *lnodes = leaves + 4 * bv.n_slots, *lleaves = lnodes + 4 * lbv.n_nodes;
-        ws.n_top = bvh_stage_top(bv, nodes, bv.n_nodes);
+        // node records are 80 bytes = 5 float4, leaf records 4 float4
+        v4f *nodes = scene_mem, *leaves = nodes + 5 * bv.n_nodes;
+        v4f *lnodes = leaves + 4 * bv.n_slots, *lleaves = lnodes + 5 * lbv.n_nodes;
+        bvh_stage_nodes_resident(bv, (float *)nodes);
+        ws.n_top = bv.n_nodes;
         ws.leaves = (lds_v4f_ptr)leaves;
         bvh_stage_leaves(bv, leaves);
         lws.top = (lds_v4f_ptr)lnodes;
         lws.leaves = (lds_v4f_ptr)lleaves;
         if (with_light) {
-            lws.n_top = bvh_stage_top(lbv, lnodes, lbv.n_nodes);
+            bvh_stage_nodes_resident(lbv, (float *)lnodes);
+            lws.n_top = lbv.n_nodes;
             bvh_stage_leaves(lbv, lleaves);
         }
         share = (lds_u8_ptr)share_mem + 128 * wv;
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     ts.node = 0; ts.sp = 0; ts.run = false;
     Ray ray;
     ray.o = ray.d = mk3(0.0f, 0.0f, 0.0f);
-    BvhRay br = bvh_ray_setup(ray, bv.max_abs_coord);
+    BvhRay br = bvh_ray_setup<CFG::RES>(ray, bv.max_abs_coord);
     ClosestFold cf;
     closest_fold_reset(cf, 1.0f);
     for (;;) {
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
             const float4 a = b.xa[q_in][i], c = b.xb[q_in][i];
             ray.o = mk3(a.x, a.y, a.z);
             ray.d = mk3(a.w, c.x, c.y);
-            br = bvh_ray_setup(ray, bv.max_abs_coord);
+            br = bvh_ray_setup<CFG::RES>(ray, bv.max_abs_coord);
             closest_fold_reset(cf, 1.0f);
             busy = true;
             ts.node = 0; ts.sp = 0; ts.run = br.finite;
