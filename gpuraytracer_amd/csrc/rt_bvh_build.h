@@ -49,9 +49,12 @@ struct Box {
 struct Item { Box box; float c[3]; int32_t id; };
 
 // Largest leaf, by scene size: triangle tests cost about as much as node steps, and the balance moves towards smaller
-// leaves as traversals get longer (measured on MI355X: 424 triangles 3 = 4 > 2, 12 030 triangles 3 > 4, 2, 5;
+// leaves as traversals get longer (measured on MI355X: 424 triangles 5 = 4 > 3 > 2 > 6; 12 030 triangles 3 = 5 > 4, 6;
 // 1 M triangles 2 > 3 > 4).  The leaf code holds up to 7.
-inline int max_leaf_for(uint32_t count) { return count >= 65536u ? 2 : 3; }
+#ifndef RT_SMALL_LEAF
+#define RT_SMALL_LEAF 4
+#endif
+inline int max_leaf_for(uint32_t count) { return count >= 65536u ? 2 : (count < 2048u ? RT_SMALL_LEAF : 3); }
 #ifndef RT_BVH_BINS
 #define RT_BVH_BINS 32
 #endif

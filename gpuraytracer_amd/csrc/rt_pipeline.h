@@ -82,7 +82,10 @@ RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
 #define RT_MIN_WAVES 4                               // waves per SIMD the traversal kernels are compiled for (register budget)
 #endif
 constexpr int RES_STACK = RT_RES_STACK;              // traversal stack entries of the resident form (hierarchy depth < RES_STACK)
-constexpr int RES_BYTES = 46 * 1024;                 // room for the resident records: 80 bytes per node, 64 per leaf slot, both hierarchies
+#ifndef RT_RES_KB
+#define RT_RES_KB 46
+#endif
+constexpr int RES_BYTES = RT_RES_KB * 1024;                 // room for the resident records: 80 bytes per node, 64 per leaf slot, both hierarchies
 template <bool BVH_, int SHARE_, bool RES_>
 struct KernelCfg {
     static constexpr bool BVH = BVH_;
