@@ -10,17 +10,21 @@ One step renders `--spp-per-step` samples per pixel (64 by default); the default
 1024 spp of the metric, so `seconds_to_1024spp` is the timed region itself.  Rays = findIntersection
 executions (one per bounce entered); light probes are counted separately.
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders the same number
-of samples per pixel with SAMPLE = rank + N*k (weak scaling), the scene is replicated, and the
-per-GPU radiance sums are added onto rank 0 by one RCCL reduce inside the timed region.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the scene is replicated and rank r renders
+SAMPLE = r, r + N, r + 2N, ...; the per-GPU radiance sums are gathered on rank 0 over RCCL and added there in rank
+order, inside the timed region.  Two modes:
+  default          every rank renders steps x spp-per-step samples ("scaling": "weak")
+  --total-spp T    the T samples of one image are split over the ranks ("scaling": "strong"; the step count follows
+                   from T); with --width 3840 --height 2160 --total-spp 4096 this is the 4K / 4096 spp configuration
 
 Other workloads (not the headline; `--workload`): `obiwan` = the bundled 12 030-triangle model at RECURSION 16,
-`c3` = a synthetic 1 M-triangle textured height field (gpuraytracer_amd/synthetic.py) ingested through the
-OBJ/MTL reader.
+`c3` = a synthetic 1 M-triangle height field (gpuraytracer_amd/synthetic.py) ingested through the OBJ/MTL reader,
+with 4096^2 albedo / normal / ARM layers that go through OpenEXR files like the reference's loadMaterial.
 
 Rank 0 prints one JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,11 +36,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-# FP32 vector rate without fused multiply-add: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (one flop per lane
-# and clock); half of the 157.3 TFLOP/s FMA figure.  The intersection arithmetic may not contract.  Reaching
-# this rate takes packed instructions (two flops per lane and issue slot); plain wave64 instructions sustain
-# one per 4 clocks and SIMD, half of it (tools/microbench_valu.hip).
-PEAK_VALU_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# Vector-instruction issue of gfx950 as measured by tools/microbench_valu.hip (profiles/r02_valu_ceiling.txt): a SIMD
+# sustains one wave64 instruction per 2.32 clocks for v_fma/v_mul/v_add/v_mov/integer add/logic (and for mixes of those
+# with the slower kinds), one per 4.2 clocks for v_min/v_max/v_cmp/v_cndmask/shifts/conversions/packed f32.
+VALU_FAST_CLOCKS = 2.32
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+# FP32 rate of unfused multiplies and adds (the intersection arithmetic may not contract): one flop per lane and
+# instruction at the fast issue rate above
+PEAK_VALU_TFLOPS = SIMDS * 64 * CLOCK_HZ / VALU_FAST_CLOCKS / 1e12
 FLOPS_PER_CLOSEST_TEST = 35     # raytracer.glsl:135-158, full pass
 FLOPS_PER_PROBE_TEST = 34       # raytracer.glsl:171-195
 
@@ -47,27 +54,54 @@ def constant_env():
     return env
 
 
+def kernel_source_fingerprint():
+    """SHA-256 over the kernel sources: counter files under profiles/ carry the fingerprint of the sources they were
+    measured on, and are used only while it still matches."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "gpuraytracer_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(scene, cam, clock, recursion, budget_s=12.0):
     """The CPU restatement (oracle/, C-library math, OpenMP) on a bounded sample of the same workload:
-    whole 1080p frames of consecutive SAMPLE indices, as many as fit the time budget."""
+    whole frames of consecutive SAMPLE indices, as many as fit the time budget."""
     from oracle import oracle
-    RECURSION = recursion
     sc = oracle.OracleScene(*scene, libm=True)
     sc.upload_env(constant_env())
     t0 = time.perf_counter()
-    _, st = sc.render(cam, clock, RECURSION, 1.0, W, H, 0, 1)
+    _, st = sc.render(cam, clock, recursion, 1.0, W, H, 0, 1)
     t1 = time.perf_counter() - t0
     spp = int(max(1, min(32, budget_s / max(t1, 1e-3))))
     t0 = time.perf_counter()
-    _, st = sc.render(cam, clock, RECURSION, 1.0, W, H, 0, spp)
+    _, st = sc.render(cam, clock, recursion, 1.0, W, H, 0, spp)
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%dx%d, SAMPLE 0..%d (%d rays) in %.2f s, OpenMP over pixels" % (W, H, spp - 1, st["rays"], dt)}
 
 
+def llvmpipe_baseline():
+    """The reference's own shader under Mesa llvmpipe cannot run on the GPU box (no reference, no Mesa there); the time
+    it took in the build container for configuration 1 is carried along with the fixture it produced."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "ref_c1_cubes512.json")) as f:
+            c1 = json.load(f)
+        secs = float(c1["llvmpipe_seconds_16spp"])
+    except (OSError, ValueError, KeyError):
+        return None
+    rays = float(c1.get("rays_16spp", 0)) or 512 * 512 * 16 * 1.2557
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "kind": "reference",
+            "cores": int(c1.get("llvmpipe_threads", 8)),
+            "sample": "cubes 512x512, SAMPLE 0..15 in %.2f s: the reference's raytracer.glsl under Mesa llvmpipe, measured in "
+                      "the build container (%d threads), not on this machine" % (secs, int(c1.get("llvmpipe_threads", 8)))}
+
+
 def load_workload(g, args):
-    """Returns (scene tuple, camera, recursion, description, texture uploads or None)."""
+    """Returns (scene tuple, camera, recursion, description, texture layers or None)."""
     if args.workload == "cubes":
         scene = g.read_rtscene(os.path.join(ROOT, "tests", "golden", "scenes", "cubes.rtscene"))
         return scene, g.camera_matrix(), 6, "cubes 424 tris", None
@@ -80,25 +114,36 @@ def load_workload(g, args):
         base = os.path.join(tmp, "grid")
         synthetic.write_displaced_grid(base, args.grid)
         scene = host.load_wavefront(base)
+        # the three texture layers travel as OpenEXR files, as the reference's loadMaterial reads them
+        # (Scene.cpp:75-102, :206-229: <name>_albedo.exr, _normal.exr, _arm.exr into 4096^2 atlas layers)
+        layers = []
+        for k, (suffix, pixels) in enumerate(zip(("albedo", "normal", "arm"), synthetic.texture_layers(args.atlas))):
+            path = os.path.join(tmp, "synthetic_%s.exr" % suffix)
+            host.write_exr(path, pixels[..., :3])
+            layers.append(host.read_exr(path))
+            os.remove(path)
     cam = g.camera_matrix((0.0, 2.2, -5.5), (-0.45, 0.0))
-    layers = synthetic.texture_layers(args.atlas)
-    return scene, cam, 6, "synthetic height field %d tris, %d^2 atlas on 2 materials" % (len(scene[0]), args.atlas), layers
+    return (scene, cam, 6, "synthetic height field %d tris, %d^2 atlas layers from OpenEXR files on 2 materials"
+            % (len(scene[0]), args.atlas), layers)
 
 
-def profile_counters(kernel_key):
-    """Per-launch counters of one kernel from the committed rocprofv3 passes over this command (separate --pmc
-    runs, tools/prof_bench.sh): FETCH_SIZE_KB (to be doubled: gfx950 reports half of wide reads), WRITE_SIZE_KB,
-    vector instructions and vector-unit busy fraction."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+def profile_counters(workload, kernel_key):
+    """Per-launch counters of one kernel from rocprofv3 passes over this command (separate --pmc runs, made by
+    tools/prof_bench.sh and tools/prof_summary.py and kept under profiles/): FETCH_SIZE_KB (to be doubled: gfx950
+    reports half of wide reads), WRITE_SIZE_KB, vector instructions.  Returns (counters, provenance) or (None, why)."""
+    name = "r02_pmc_counters_%s.json" % workload
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             table = json.load(f)
     except (OSError, ValueError):
-        return None
-    for name, counters in table.items():       # template arguments follow the name: "k_first<true, 1>"
-        if name.startswith(kernel_key):
-            return counters
-    return None
+        return None, "no counter file profiles/%s" % name
+    meta = table.get("_meta", {})
+    if meta.get("kernel_source_fingerprint") != kernel_source_fingerprint():
+        return None, "profiles/%s was measured on other kernel sources (fingerprint %s)" % (name, meta.get("kernel_source_fingerprint"))
+    for kernel, counters in table.items():
+        if kernel.startswith(kernel_key):
+            return counters, "profiles/%s: separate rocprofv3 --pmc passes of `%s`, same kernel sources" % (name, meta.get("command", "?"))
+    return None, "profiles/%s has no kernel %s" % (name, kernel_key)
 
 
 def main():
@@ -107,28 +152,39 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="strong scaling: split this many samples per pixel over the ranks (the step count follows from it)")
     ap.add_argument("--batch-samples", type=int, default=64, help="samples per pass (about 290 bytes of queue memory per pixel-sample of a pass)")
     ap.add_argument("--pipeline", type=int, default=1)
     ap.add_argument("--accel", type=int, default=-1, help="-1 auto, 0 loops over all triangles, 1 hierarchy")
     ap.add_argument("--workload", choices=("cubes", "obiwan", "c3"), default="cubes")
     ap.add_argument("--grid", type=int, default=724, help="c3: cells per side of the height field")
-    ap.add_argument("--atlas", type=int, default=1024, help="c3: edge of the texture layers")
+    ap.add_argument("--atlas", type=int, default=4096, help="c3: edge of the texture layers")
     ap.add_argument("--refill", type=int, default=-1, help="-1 library default, 0/1 closest-hit kernels without/with lane refill")
     ap.add_argument("--resident", type=int, default=-1, help="-1 library default, 0 never stage a whole hierarchy into LDS")
     ap.add_argument("--share", type=int, default=-1, help="-1 library default; 0/1 any-hit searches shared among the lanes of a wave")
     ap.add_argument("--staged-depths", type=int, default=-2, help="-2 library default; bounces after the first that run staged before the tail kernel (-1 all)")
     ap.add_argument("--width", type=int, default=1920, help="target width (the headline metric is quoted at 1920 x 1080)")
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--lane-utilisation", action="store_true",
-                    help="cubes/obiwan: add the lane utilisation of the traversal loops (two extra 32 spp renders in child processes)")
+    ap.add_argument("--unordered-reduce", action="store_true", help="N > 1: one RCCL reduce(SUM) instead of gather + add in rank order")
+    ap.add_argument("--lane-utilisation", type=int, default=-1,
+                    help="add the lane utilisation of the traversal loops (two extra 32 spp renders in child processes); "
+                         "-1: only for --workload obiwan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
     global W, H
     W, H = args.width, args.height
 
+    # Libraries underneath write to the process's standard output (RCCL prints a version banner at its first
+    # collective); the contract is ONE JSON line there, so everything else goes to standard error.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import gpuraytracer_amd as g
+    from gpuraytracer_amd.distributed import reduce_sums, shard_samples
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -146,6 +202,15 @@ def main():
 
     scene, cam, RECURSION, workload_name, layers = load_workload(g, args)
     clock = g.DEFAULT_CLOCK
+    spp = args.spp_per_step
+    strong = args.total_spp > 0
+    if strong:
+        # this rank's share of the image's samples, rendered in steps of `spp`; every rank times the same step count
+        _, my_count, _ = shard_samples(args.total_spp, rank, world)
+        steps = (shard_samples(args.total_spp, 0, world)[1] + spp - 1) // spp
+    else:
+        my_count = args.steps * spp
+        steps = args.steps
 
     ctx = g.Context(local_rank)
     ctx.set_option("pipeline", args.pipeline)
@@ -173,17 +238,19 @@ def main():
                 ctx.upload_atlas_layer(m, k, layers[k])
             flags[m] = 1
         ctx.set_has_texture(flags)
+        layers = None
     ctx.upload_env(constant_env())
     ctx.resize(W, H)
     sums = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")     # accumulation buffer (float4 per pixel)
     ctx.set_sum_buffer(sums.data_ptr())
     ctx.set_frame(cam, clock, RECURSION, 1.0)
 
-    spp = args.spp_per_step
-
     def step(i):
-        # SAMPLE indices of this rank: rank + world * k
-        ctx.trace(rank + world * (i * spp), spp, world)
+        # SAMPLE indices of this rank: rank + world * k for k in [i * spp, (i + 1) * spp), cut at this rank's share
+        first = i * spp
+        n = min(spp, my_count - first) if i < steps else spp
+        if n > 0:
+            ctx.trace(rank + world * first, n, world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -192,94 +259,107 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(args.steps + i)
+        step(steps + i)
+    if dist is not None:                       # the first collective sets up the communicator: not inside the timed region
+        reduce_sums(sums, dst=0, ordered=not args.unordered_reduce)
     barrier()
     sums.zero_()
     ctx.reset_stats()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
+    torch.cuda.synchronize()
+    t_render = time.perf_counter()
     if dist is not None:
-        dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
+        reduce_sums(sums, dst=0, ordered=not args.unordered_reduce)
     barrier()
-    dt = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    dt = t_end - t0
+    reduce_ms = (t_end - t_render) * 1e3       # reduce and the closing barrier (which also absorbs the ranks' skew)
 
     st = ctx.stats()
-    tot = torch.tensor([float(st["rays"]), float(st["shadow_probes"] + st["glossy_probes"]), dt],
+    tot = torch.tensor([float(st["rays"]), float(st["shadow_probes"] + st["glossy_probes"]), dt, reduce_ms, float(my_count)],
                        dtype=torch.float64, device="cuda")
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax[2])
-    rays, probes = float(tot[0]), float(tot[1])
+        dt, reduce_ms = float(tmax[2]), float(tmax[3])
+    rays, probes, total_samples = float(tot[0]), float(tot[1]), int(tot[4])
 
     if rank == 0:
-        img = sums.view(H, W, 4)[..., :3] / float(args.steps * spp * world)
+        img = sums.view(H, W, 4)[..., :3] / float(total_samples)
         finite = torch.isfinite(img).all(dim=2)
         # the shader's sqrt(1 - cos^2) (raytracer.glsl:204) goes NaN when a rounded cosine exceeds 1; such
         # samples poison their pixel in the reference too, and are reproduced here
         nonfinite_pixels = int((~finite).sum().item())
         mean = img[finite].mean().item()
-        # largest kernel: the depth-0 extend launches (closest hit of one camera ray per pixel-sample + shading)
+        # dominant kernel: the depth-0 launches (camera ray, closest hit, shading, probe in place, rest of the bounce);
+        # their time comes from HIP events on the context's stream (rt_stats), recorded inside the timed region
         ext_ms, ext_n = st["extend0_ms"], max(1, st["extend0_launches"])
         used_bvh = st["bvh_extend_nodes"] > 0
         if used_bvh:
-            # Depth-0 kernel (camera ray, closest hit by hierarchy, shading, light probe in place, rest of the
-            # bounce).  Nodes and triangles come from LDS/L1/L2; what has to cross HBM is what the stage leaves
-            # behind: a 16-byte radiance record per path that ended, a 64-byte path record per path that goes on.
+            # Nodes and triangles come from LDS/L1/L2; what has to cross HBM is what the stage leaves behind: a 16-byte
+            # radiance record per path that ended, a 64-byte path record per path that goes on.
             d1 = float(st["depth1_paths"])
             algo = (float(st["pixel_samples"]) - d1) * 16.0 + d1 * 64.0
             achieved = algo / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-            prof = profile_counters("k_first<true") if args.workload == "cubes" else None
-            roof = {"bound": "hbm", "kernel": "k_first<BVH> (depth 0: camera ray, closest hit by hierarchy, shading, "
+            prof, provenance = profile_counters(args.workload, "k_first<")
+            comparable = prof is not None and args.spp_per_step == 64 and (W, H) == (1920, 1080)
+            roof = {"bound": "hbm", "kernel": "k_first (depth 0: camera ray, closest hit by hierarchy, shading, "
                                               "light probe in place, rest of the bounce)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": (2.0 * prof["FETCH_SIZE_KB"] + prof["WRITE_SIZE_KB"]) * 1024.0 if prof else None,
+                    "traffic": (2.0 * prof["FETCH_SIZE_KB"] + prof["WRITE_SIZE_KB"]) * 1024.0 if comparable else None,
+                    "traffic_source": provenance if comparable else "not measured for this configuration (%s)" % provenance,
                     "bytes_per_launch": algo / ext_n,
-                    "note": "bound by vector instruction issue, not by bandwidth: see valu_issue"}
-            if prof and ext_ms > 0:
-                # vector instructions of one launch (committed counter pass of this command) over the live launch time,
-                # against the sustained issue rate of wave64 vector instructions without packed math
-                # (tools/microbench_valu.hip: one per 4 clocks and SIMD; 1024 SIMDs at 2.4 GHz)
-                peak = 1024 * 2.4e9 / 4.0 / 1e9
+                    "note": "bound by vector instruction issue and the latency of dependent LDS accesses, not by "
+                            "bandwidth: see valu_issue"}
+            if comparable and ext_ms > 0:
+                # vector instructions of one launch (counter pass) over the live launch time, against the issue rate a
+                # SIMD sustains (profiles/r02_valu_ceiling.txt)
+                peak = SIMDS * CLOCK_HZ / VALU_FAST_CLOCKS / 1e9
                 rate = prof["valu_wave_insts"] / (ext_ms / ext_n * 1e-3) / 1e9
                 roof["valu_issue"] = {"bound": "valu", "achieved": rate, "peak": peak, "unit": "G wave-instructions/s",
-                                      "frac": rate / peak, "counter_busy_frac": prof["valu_busy_frac"],
-                                      "wave_insts_per_launch": prof["valu_wave_insts"]}
+                                      "frac": rate / peak, "wave_insts_per_launch": prof["valu_wave_insts"],
+                                      "peak_source": "profiles/r02_valu_ceiling.txt: one wave64 instruction per %.2f clocks "
+                                                     "and SIMD (4.2 for min/max/compare/select), 1024 SIMDs, 2.4 GHz" % VALU_FAST_CLOCKS,
+                                      "insts_source": provenance}
         else:
             flops = float(st["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
             achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0
-            roof = {"bound": "valu", "kernel": "k_first<false> (depth 0 with loops over all triangles)",
+            roof = {"bound": "valu", "kernel": "k_first (depth 0 with loops over all triangles)",
                     "achieved": achieved, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_VALU_TFLOPS, "traffic": None, "flops_per_launch": flops / ext_n,
                     "note": "closest-hit tests only; the launch also runs the probe loops of depth 0"}
         roof.update({"avg_launch_ms": ext_ms / ext_n, "launches": int(st["extend0_launches"]),
                      "probe_kernels_ms": st["probe_ms"], "extend_kernels_ms": st["extend_ms"],
                      "shade_kernels_ms": st["shade_ms"]})
+        spp_label = ("%d spp split over %d GPUs" % (args.total_spp, world)) if strong else "%d spp per GPU" % (steps * spp)
         out = {
             "metric": "Mrays/s (paths x bounces) at 1080p" if (W, H) == (1920, 1080) else "Mrays/s (paths x bounces) at %dx%d" % (W, H),
             "value": rays / dt / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": dt / max(1, steps) * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s, %dx%d, RECURSION %d, %d spp per GPU (%d spp/step), "
-                                   "constant environment" % (workload_name, W, H, RECURSION, args.steps * spp, spp),
+            "config": {"workload": "%s, %dx%d, RECURSION %d, %s (%d spp/step), constant environment"
+                                   % (workload_name, W, H, RECURSION, spp_label, spp),
                        "pipeline": "staged" if args.pipeline else "single-kernel",
                        "closest_hit": "hierarchy (exact)" if used_bvh else "loop over all triangles",
-                       "parallelism": "spp split x%d + RCCL reduce" % world if world > 1 else "1 GPU"},
-            "seconds_to_%dspp" % (args.steps * spp): dt,
+                       "parallelism": ("spp split x%d, sums gathered over RCCL and added in rank order" % world) if world > 1 else "1 GPU"},
+            "seconds_to_%dspp" % (args.total_spp if strong else steps * spp): dt,
+            "reduce_ms": reduce_ms if dist is not None else 0.0,
             "probe_rays_per_s_M": probes / dt / 1e6,
             "rays_per_pixel_sample": rays / max(1.0, float(st["pixel_samples"]) * world),
             "mean_radiance": mean,
             "nonfinite_pixels": nonfinite_pixels,
             "bvh": {k: st[k] for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris")},
+            "queue_memory_bytes": int(st["queue_bytes"]),
             "scene_upload_s": upload_s,
             "roofline": roof,
         }
@@ -303,15 +383,15 @@ def main():
                   + float(s1["shadow_probes"] + s1["glossy_probes"]) * (n_tri - 1) * FLOPS_PER_PROBE_TEST)
             a1 = f1 / (s1["extend0_ms"] * 1e-3) / 1e12 if s1["extend0_ms"] > 0 else 0.0
             out["roofline_bruteforce"] = {
-                "bound": "valu", "kernel": "k_first<false> (depth 0 with loops over all %d triangles: closest hit, "
+                "bound": "valu", "kernel": "k_first (depth 0 with loops over all %d triangles: closest hit, "
                                            "shading, light probe)" % n_tri,
                 "achieved": a1, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s", "frac": a1 / PEAK_VALU_TFLOPS,
                 "avg_launch_ms": s1["extend0_ms"] / max(1, s1["extend0_launches"]),
                 "flops_per_launch": f1 / max(1, s1["extend0_launches"]),
                 "value_Mrays_per_s": s1["rays"] / dt1 / 1e6, "sample": "64 spp, RECURSION 1",
-                "note": "flops counted as full tests; triangles whose plane test fails for the whole wave skip the "
-                        "rest, and plain (unpacked) instructions sustain half of the peak"}
-        if args.lane_utilisation and world == 1 and args.workload in ("cubes", "obiwan"):
+                "note": "flops counted as full tests; triangles whose plane test fails for the whole wave skip the rest"}
+        want_lanes = args.lane_utilisation == 1 or (args.lane_utilisation < 0 and args.workload == "obiwan")
+        if want_lanes and world == 1 and args.workload in ("cubes", "obiwan"):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import lane_utilisation
             out["lane_utilisation"] = lane_utilisation.measure(args.workload, RECURSION)
@@ -320,7 +400,10 @@ def main():
             out["cpu_baseline"] = None
         elif not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, cam, clock, RECURSION)
-        print(json.dumps(out))
+        if args.workload == "cubes":
+            out["cpu_baseline_llvmpipe"] = llvmpipe_baseline()
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -11,7 +11,7 @@ from conftest import constant_env, load_scene
 from gpuraytracer_amd.camera import camera_matrix, DEFAULT_CLOCK
 from gpuraytracer_amd.distributed import mean_image, reduce_sums, shard_samples
 
-W, H, SPP = 24, 16, 7
+W, H, SPP = 24, 16, 7          # 7 samples: 4 + 3 on two ranks, 3 + 2 + 2 on three
 
 
 def test_shard_samples_partition():
@@ -47,16 +47,24 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_split_and_reduce(tmp_path, oracle_mod):
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_and_ordered_reduce(tmp_path, oracle_mod, world):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "sum.npy")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    got = mean_image(np.load(out), SPP, W, H)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    total = np.load(out).reshape(H, W, 4)[..., :3]
     sc = oracle_mod.OracleScene(*load_scene("cubes"))
     sc.upload_env(constant_env())
-    want, _ = sc.render(camera_matrix(), DEFAULT_CLOCK, 6, 1.0, W, H, 0, SPP)
-    # same samples, different association of the float sum
-    assert np.allclose(got, want / SPP, rtol=1e-5, atol=1e-6)
+    # the reduce adds the per-rank sums in ascending rank order: reproduce exactly that here
+    want = None
+    for rank in range(world):
+        begin, count, stride = shard_samples(SPP, rank, world)
+        part, _ = sc.render(camera_matrix(), DEFAULT_CLOCK, 6, 1.0, W, H, begin, count, stride)
+        want = part if want is None else (want + part).astype(np.float32)
+    assert np.array_equal(total.view(np.uint32), want.view(np.uint32))
+    # and against all samples summed in SAMPLE order on one device: same samples, another association of the float sum
+    one, _ = sc.render(camera_matrix(), DEFAULT_CLOCK, 6, 1.0, W, H, 0, SPP)
+    assert np.allclose(mean_image(np.load(out), SPP, W, H), one / SPP, rtol=1e-5, atol=1e-6)
