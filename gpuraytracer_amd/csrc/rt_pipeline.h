@@ -71,6 +71,50 @@ RT_DEV uint32_t wave_index() {
 }
 RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
 
+// Order in which the depth-0 kernel hands the 64-path chunks of a round (PIPE_WAVES chunks) to its waves.  Workgroups are
+// dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has an L2 of its own: with the plain
+// order chunk = wave, each L2 sees 8-tile pieces from all over the round's band of the image and so the whole of the
+// hierarchy under it.  Here the waves of one XCD take one contiguous eighth of the round's chunks instead, so that an
+// L2 serves one compact patch of the image.  (A wave's queue region stays its own, so the deeper stages of those
+// paths run on the same XCD as well.)
+#ifndef RT_XCD_ORDER
+#define RT_XCD_ORDER 1
+#endif
+#ifndef RT_TILE_MAJOR
+#define RT_TILE_MAJOR 1
+#endif
+constexpr uint32_t N_XCD = 8;
+static_assert((PIPE_WAVES / WG_WAVES) % N_XCD == 0, "workgroups divide evenly among the XCDs");
+RT_DEV uint32_t first_chunk_of_wave() {
+    if (!RT_XCD_ORDER) return wave_index();
+    const uint32_t wg = blockIdx.x, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    return (wg % N_XCD) * (uint32_t)(PIPE_WAVES / N_XCD) + (wg / N_XCD) * (uint32_t)WG_WAVES + wv;
+}
+
+// Numbering of the 8x8 pixel tiles of the target: vertical strips of TILE_STRIP tiles' width, row-major inside a
+// strip (the last strip may be narrower), so that a run of consecutive tile numbers is a compact block of the image
+// rather than a thin line across it (512 tiles at 16 tiles' width: 128 x 256 pixels).
+#ifndef RT_TILE_STRIP
+#define RT_TILE_STRIP 16
+#endif
+constexpr uint32_t TILE_STRIP = RT_TILE_STRIP;
+RT_DEV void tile_position(uint32_t tile, uint32_t tiles_x, uint32_t tiles_y, uint32_t &tx, uint32_t &ty) {
+    if (TILE_STRIP == 0) { tx = tile % tiles_x; ty = tile / tiles_x; return; }
+    const uint32_t strip = tile / (TILE_STRIP * tiles_y);
+    const uint32_t rest = tile - strip * (TILE_STRIP * tiles_y);
+    const uint32_t left = tiles_x - strip * TILE_STRIP;
+    const uint32_t w = left < TILE_STRIP ? left : TILE_STRIP;
+    ty = rest / w;
+    tx = strip * TILE_STRIP + (rest - ty * w);
+}
+RT_DEV uint32_t tile_number(uint32_t tx, uint32_t ty, uint32_t tiles_x, uint32_t tiles_y) {
+    if (TILE_STRIP == 0) return ty * tiles_x + tx;
+    const uint32_t strip = tx / TILE_STRIP;
+    const uint32_t left = tiles_x - strip * TILE_STRIP;
+    const uint32_t w = left < TILE_STRIP ? left : TILE_STRIP;
+    return strip * (TILE_STRIP * tiles_y) + ty * w + (tx - strip * TILE_STRIP);
+}
+
 // Compile-time form of a traversal kernel.
 //   BVH    hierarchy traversal (false: the reference's loops over all triangles)
 //   SHARE  any-hit searches shared among the lanes of a wave: 0 off, 1 on, 2 on with a node-step budget per round
@@ -299,9 +343,10 @@ RT_DEV void store_route_fill(const PipeBuffers &b, int q_in, const RouteFill &fi
 // Returns false for the padding lanes of ragged tiles.
 RT_DEV bool first_path(const DFrame &fr, uint32_t sample, uint32_t in_sample, uint32_t tiles_x, bool live, PathState &ps) {
     const uint32_t lane = lane_index();
-    const uint32_t tile = in_sample >> 6;
-    const uint32_t tx = (tile % tiles_x) * 8u + (lane & 7u);
-    const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
+    uint32_t tile_x, tile_y;
+    tile_position(in_sample >> 6, tiles_x, (fr.height + 7u) >> 3, tile_x, tile_y);
+    const uint32_t tx = tile_x * 8u + (lane & 7u);
+    const uint32_t ty = tile_y * 8u + (lane >> 3);
     ps.seed = pixel_seed(fr, tx, ty, sample);
     const Ray cam = camera_ray(fr, tx, ty, ps.seed);
     ps.o = cam.o; ps.d = cam.d;
@@ -378,13 +423,27 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
 #define SECTION_MARK(k) do { } while (0)
 #define RT_SECTION_CLOCKS 0
 #endif
-    for (uint32_t base = wave * 64u; base < total; base += (uint32_t)PIPE_WAVES * 64u) {
+    // A chunk is one tile of one sample.  Chunks are numbered tile-major (all samples of a tile follow each other), so
+    // that the waves at work at the same time are on few tiles: the nodes and triangles under a tile are fetched once
+    // and then found in the caches by the tile's other samples (slot-major order meets a tile again only after the whole
+    // image, i.e. after the whole scene, has gone through the caches).
+    const uint32_t n_chunks = (paths_per_sample >> 6) * tab.n;
+    for (uint32_t chunk = first_chunk_of_wave(); chunk < n_chunks; chunk += (uint32_t)PIPE_WAVES) {
 #if RT_SECTION_CLOCKS > 0
         unsigned long long mark_ = __builtin_amdgcn_s_memtime();
 #endif
+        // slot, SAMPLE and the coin are the same for the whole wave
+#if RT_TILE_MAJOR
+        // (the slot is rotated by the round: a wave whose chunks all had the same slot, as happens when the pass size
+        // divides the wave count, would draw the same coin for all its paths, and the probe stages of the next depths
+        // would find their work in half of the regions)
+        const uint32_t tile_of_chunk = chunk / tab.n;
+        const uint32_t slot = (chunk - tile_of_chunk * tab.n + chunk / (uint32_t)PIPE_WAVES) % tab.n;
+        const uint32_t base = slot * paths_per_sample + tile_of_chunk * 64u;
+#else
+        const uint32_t base = chunk * 64u, slot = base / paths_per_sample;
+#endif
         const uint32_t id = base + lane;
-        // `base` lies in one sample's range of path ids: slot, SAMPLE and the coin are the same for the whole wave
-        const uint32_t slot = base / paths_per_sample;
         PathState ps;
         const bool live = first_path(fr, tab.sample[slot], base - slot * paths_per_sample, tiles_x, id < total, ps);
         n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
@@ -818,8 +877,8 @@ __global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restri
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= width * height) return;
     const uint32_t tx = pix % width, ty = pix / width;
-    const uint32_t tiles_x = (width + 7u) >> 3;
-    const uint32_t local = ((ty >> 3) * tiles_x + (tx >> 3)) * 64u + (ty & 7u) * 8u + (tx & 7u);
+    const uint32_t tiles_x = (width + 7u) >> 3, tiles_y = (height + 7u) >> 3;
+    const uint32_t local = tile_number(tx >> 3, ty >> 3, tiles_x, tiles_y) * 64u + (ty & 7u) * 8u + (tx & 7u);
     float4 s = sum[pix];
     for (uint32_t k = 0; k < n_slots; k++) {
         const float4 e = b.energy[(size_t)k * paths_per_sample + local];
