@@ -45,6 +45,7 @@ struct rt_context {
         float max_abs = 0.0f;
         int n_nodes = 0, n_slots = 0, depth = 0;
         bool ok = false;
+        bool tiny_normals = false;     // HostBvh::min_normal_len2 < TINY_NORMAL_LEN2
     };
     DevBvh bvh, light_bvh;
     int accel = -1;            // -1 auto (hierarchy from ACCEL_AUTO_MIN triangles on), 0 brute force, 1 hierarchy
@@ -141,7 +142,8 @@ DBvh device_bvh(const rt_context *ctx, const rt_context::DevBvh &b, bool want) {
 
 bool use_accel(const rt_context *ctx) {
     if (!ctx->bvh.ok) return false;
-    if (ctx->accel < 0) return ctx->count >= ACCEL_AUTO_MIN;
+    // automatic choice: scenes too small to gain, and scenes whose depth comparisons can underflow, keep the loops
+    if (ctx->accel < 0) return ctx->count >= ACCEL_AUTO_MIN && !ctx->bvh.tiny_normals;
     return ctx->accel != 0;
 }
 
@@ -174,6 +176,7 @@ hipError_t upload_bvh(const rt_triangle_model *tris, uint32_t count, rt_context:
     out.n_nodes = (int)(hb.nodes.size() / 16);
     out.n_slots = (int)hb.leaf_ids.size();
     out.depth = hb.depth;
+    out.tiny_normals = hb.min_normal_len2 < TINY_NORMAL_LEN2;
     out.ok = e == hipSuccess;
     return e;
 }

@@ -31,7 +31,13 @@ struct HostBvh {
     std::vector<int32_t> leaf_ids;     // original triangle index per leaf slot
     int depth = 0;
     float max_abs_coord = 0.0f;        // largest |coordinate| of any vertex
+    // Smallest non-zero |true_normal|^2 of any triangle.  The reference compares depths as cross-multiplied products
+    // rd_a * det_b (raytracer.glsl:150), both factors scaling with |normal|; where such products underflow the
+    // comparison is "not farther" for every pair and the later index wins whatever the depths, which a traversal
+    // that prunes by depth does not reproduce.  Callers keep to the loop over all triangles below TINY_NORMAL_LEN2.
+    double min_normal_len2 = INFINITY;
 };
+constexpr double TINY_NORMAL_LEN2 = 8.271806125530277e-25;      // 2^-80: |cross(u, v)| below 2^-40, edges below about 1e-6
 
 namespace bvh_detail {
 
@@ -88,6 +94,9 @@ inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool f
             if (std::isfinite(it.box.lo[a])) max_abs = std::max(max_abs, std::max(std::fabs(it.box.lo[a]), std::fabs(it.box.hi[a])));
         }
         it.id = (int32_t)i;
+        const double n2 = (double)t.true_normal[0] * t.true_normal[0] + (double)t.true_normal[1] * t.true_normal[1] +
+                          (double)t.true_normal[2] * t.true_normal[2];
+        if (n2 > 0.0 && n2 < out.min_normal_len2) out.min_normal_len2 = n2;
     }
     out.nodes.clear();
     out.leaf_geo.clear();

@@ -406,11 +406,11 @@ struct Bounce {
 };
 
 // global_light (:557) of a bounce whose coin chose sampleLight: spec_light is zero, so the second term
-// (specular * 0) * w is a zero of either sign for finite inputs and is left out.
+// (specular * 0) * w is a zero of either sign for finite inputs; shade_pre folds what it does for other inputs into `albedo`.
 RT_DEV f3 diffuse_global_light(f3 albedo, float roughness, f3 diff_light) {
     return ((albedo * diff_light) * roughness) * 2.0f;
 }
-// ... and of a bounce whose coin chose sampleLightGlossy (the term (albedo * 0) * roughness left out).
+// ... and of a bounce whose coin chose sampleLightGlossy (the term (albedo * 0) * roughness folded into `specular`).
 RT_DEV f3 glossy_global_light(f3 specular, float w, f3 spec_light) {
     return ((specular * spec_light) * w) * 2.0f;
 }
@@ -542,15 +542,21 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
     bn.lit = mk3(0.0f, 0.0f, 0.0f);
     bn.albedo = albedo;
     bn.roughness = roughness;
+    // global_light (:557) is a sum of a diffuse and a specular term, and the term of the function the coin did not
+    // choose is (colour * 0) * factor: a zero for finite inputs, but NaN when a texel made the colour or the factor
+    // infinite or NaN.  That is all the term can do, so it is folded into the colour of the term that is kept
+    // (x + 0 = x, x + NaN = NaN) instead of being carried through the probe.
+    const float spec_w = fresnel + 1.0f - roughness;
     if (coin_diffuse) {                                                                    // :553-554
+        bn.albedo = albedo + (specular * 0.0f) * spec_w;
         if (sample_light_setup(sc, ps.o, normal, ps.seed, bn.probe_d, bn.max_t, bn.lit)) bn.kind = PROBE_SHADOW;
     } else {                                                                               // :555-556, :398-401
         // position - view.position; Mesa: simplified to direction * t, the vector that was just added
         const f3 viewDir = normalize(travelled);
         bn.probe_d = reflect(viewDir, normalize(random_sphere(ps.seed) * roughness + normal));
         bn.kind = PROBE_GLOSSY;
-        bn.c = specular;
-        bn.w = fresnel + 1.0f - roughness;
+        bn.c = specular + (albedo * 0.0f) * roughness;
+        bn.w = spec_w;
     }
 }
 

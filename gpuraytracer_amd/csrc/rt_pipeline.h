@@ -437,8 +437,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         // (the slot is rotated by the round: a wave whose chunks all had the same slot, as happens when the pass size
         // divides the wave count, would draw the same coin for all its paths, and the probe stages of the next depths
         // would find their work in half of the regions)
-        const uint32_t tile_of_chunk = chunk / tab.n;
-        const uint32_t slot = (chunk - tile_of_chunk * tab.n + chunk / (uint32_t)PIPE_WAVES) % tab.n;
+        // (the amount depends on the tile alone, so that the chunks of a tile still cover every slot once)
+        const uint32_t tile_of_chunk = chunk / tab.n, first_of_tile = tile_of_chunk * tab.n;
+        const uint32_t slot = (chunk - first_of_tile + first_of_tile / (uint32_t)PIPE_WAVES) % tab.n;
         const uint32_t base = slot * paths_per_sample + tile_of_chunk * 64u;
 #else
         const uint32_t base = chunk * 64u, slot = base / paths_per_sample;

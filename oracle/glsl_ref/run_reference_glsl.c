@@ -443,7 +443,10 @@ int main(int argc, char **argv) {
     glUniform1i(6, (GLint)sc.lights);        /* LIGHTS */
     glUniform1i(7, recursion);               /* RECURSION */
     glUniform1ui(9, clock_v);                /* CLOCK */
-    glUniform1f(13, 1.0f);                   /* EXPOSURE */
+    {   /* EXPOSURE: 1.0 as Scene.cpp:331 sets it, unless REF_EXPOSURE asks for another value */
+        const char *ex = getenv("REF_EXPOSURE");
+        glUniform1f(13, ex ? (float)atof(ex) : 1.0f);
+    }
     {   /* glTexStorage2D leaves the contents undefined: clear the target */
         float *zero = (float *)calloc((size_t)W * H, 16);
         glBindTexture(GL_TEXTURE_2D, tex[0]);

@@ -28,6 +28,7 @@ def _load(libm):
     lib = ctypes.CDLL(path)
     c = ctypes
     fp = c.POINTER(c.c_float)
+    lib.orc_set_flush_denormals.argtypes = [c.c_int]
     lib.orc_pcg_hash.restype = c.c_uint32
     lib.orc_pcg_hash.argtypes = [c.c_uint32]
     lib.orc_unit_float.restype = c.c_float
@@ -64,6 +65,12 @@ def _load(libm):
 
 def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def set_flush_denormals(on, libm=False):
+    """on: the batch entry points read denormal inputs as zero and flush denormal results to zero, as llvmpipe's
+    compiled shaders do (off by default: the product keeps denormal numbers)."""
+    _load(libm).orc_set_flush_denormals(1 if on else 0)
 
 
 def pcg_hash(k, libm=False):

@@ -639,8 +639,19 @@ V3 pixel_sample(const Scene &sc, const Frame &fr, uint32_t tx, uint32_t ty, uint
 
 // ---------------------------------------------------------------- C interface (ctypes)
 
+// llvmpipe runs its compiled shaders with denormal inputs read as zero and denormal results flushed to zero (the
+// x86 control bits DAZ and FTZ).  orc_set_flush_denormals(1) makes the batch entry points below do the same, per
+// thread and only for the duration of the call.
+static int g_flush_denormals = 0;
+struct FlushScope {
+    unsigned saved;
+    FlushScope() : saved(__builtin_ia32_stmxcsr()) { if (g_flush_denormals) __builtin_ia32_ldmxcsr(saved | 0x8040u); }
+    ~FlushScope() { __builtin_ia32_ldmxcsr(saved); }
+};
+
 extern "C" {
 
+void orc_set_flush_denormals(int on) { g_flush_denormals = on; }
 uint32_t orc_pcg_hash(uint32_t k) { return pcgHash(k); }
 float orc_unit_float(uint32_t *seed) { return unitFloat(*seed); }
 int orc_libm(void) { return ORC_LIBM; }
@@ -773,6 +784,7 @@ void orc_closest_hit_batch(const void *h, const float *o, const float *d, uint64
     const Scene *sc = (const Scene *)h;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; i++) {
+        FlushScope fpmode;
         Ray r;
         r.position = v3(&o[i * 3]);
         r.direction = v3(&d[i * 3]);
@@ -790,6 +802,7 @@ void orc_shadow_batch(const void *h, const float *o, const float *d, const float
     const Scene *sc = (const Scene *)h;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; i++) {
+        FlushScope fpmode;
         Ray r;
         r.position = v3(&o[i * 3]);
         r.direction = v3(&d[i * 3]);
@@ -811,6 +824,7 @@ void orc_pixel_samples(const void *h, const float camera[16], uint32_t clock, in
     memcpy(fr.camera, camera, sizeof(fr.camera));
     fr.clock = clock; fr.recursion = recursion; fr.exposure = exposure; fr.width = width; fr.height = height;
     Stats st = {};
+    FlushScope fpmode;
     for (uint64_t i = 0; i < n; i++) {
         const V3 c = pixel_sample(*sc, fr, xs[i], ys[i], samples[i], st);
         rgb[i * 3 + 0] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
@@ -834,6 +848,7 @@ void orc_render(const void *h, const float camera[16], uint32_t clock, int32_t r
 #pragma omp parallel
     {
         Stats st = {};
+        FlushScope fpmode;
 #pragma omp for schedule(dynamic, 256) collapse(2)
         for (int64_t y = 0; y < (int64_t)height; y++)
             for (int64_t x = 0; x < (int64_t)width; x++) {

@@ -39,9 +39,17 @@ def load_scene(name):
     return read_rtscene(os.path.join(SCENES, name + ".rtscene"))
 
 
-def textured_cubes(atlas_size=32):
+# Values at the edges of the GL_R11F_G11F_B10F upload conversion: zero, negative, below the smallest packed denormal,
+# around the smallest packed normal (2^-14), around the largest packed values (65024 for the 6-bit mantissas, 64512 for
+# the 5-bit one), far above them
+PACK_EDGE_VALUES = (0.0, -1.0, -1e-3, 1e-8, 3e-5, 6.0e-5, 6.1e-5, 6.2e-5, 1.2e-4, 64512.0, 64513.0, 65024.0, 65025.0, 70000.0, 1e9)
+
+
+def textured_cubes(atlas_size=32, edge_texels=False, nonfinite_texels=False):
     """The `cubes` scene with synthetic texture coordinates and tangents on every triangle and synthetic albedo /
     normal / ARM layers for material 2 (the ARM layer smaller than the atlas: it fills a corner only).
+    edge_texels: every fifth texel of the albedo layer carries one of PACK_EDGE_VALUES in one channel;
+    nonfinite_texels: a few texels carry Inf / NaN as well.
     Returns (scene tuple, layers {slot: rgba}, hasTexture flags)."""
     models, shadings, lights, materials = load_scene("cubes")
     rng = np.random.default_rng(5)
@@ -56,7 +64,28 @@ def textured_cubes(atlas_size=32):
     nrm = rng.uniform(0.3, 0.7, size=(S, S, 4)).astype(np.float32)
     nrm[..., 2] = rng.uniform(0.8, 1.0, size=(S, S))
     arm = rng.uniform(0.05, 1.0, size=(S * 3 // 4, S * 5 // 8, 4)).astype(np.float32)
+    if edge_texels:
+        flat = albedo.reshape(-1, 4)
+        idx = np.arange(0, len(flat), 5)
+        flat[idx, idx % 3] = np.array(PACK_EDGE_VALUES, dtype=np.float32)[(idx // 5) % len(PACK_EDGE_VALUES)]
+    if nonfinite_texels:
+        flat = albedo.reshape(-1, 4)
+        flat[7::97, 0] = np.inf
+        flat[11::101, 1] = np.nan
+        flat[13::103, 2] = -np.inf
     return (models, shadings, lights, materials), {0: albedo, 1: nrm, 2: arm}, np.array([0, 0, 1, 0], np.int32)
+
+
+def tiny_cubes(scale):
+    """The `cubes` scene scaled by a power of two so small that the triangle normals (pre-computed cross products of
+    two edges, i.e. scaled by its square) fall among the denormal numbers.  All scalings are exact."""
+    models, shadings, lights, materials = load_scene("cubes")
+    scale = np.float32(scale)
+    tiny = models.copy()
+    for field in ("position", "u", "v"):
+        tiny[field] = models[field] * scale
+    tiny["true_normal"] = models["true_normal"] * scale * scale
+    return tiny, shadings, lights, materials
 
 
 @pytest.fixture(scope="session")

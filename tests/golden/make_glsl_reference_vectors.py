@@ -17,6 +17,8 @@ Writes tests/golden/ref_*.npz; nothing of the reference's text is stored, only i
   ref_irradiance.npz the (w/4) x (h/4) image the reference's res/shader/irradiance.glsl leaves after one dispatch
                      per radiance row (Scene.cpp:150-186), for three small random environments
                      (`python tests/golden/make_glsl_reference_vectors.py irradiance` makes this file alone)
+  `... extra` makes the cases of make_extra() (EXPOSURE 0.5, texels at the edges of the packed-float upload, a scene of
+                     denormal numbers)
   ref_c1_cubes512.json   the reference's own CPU-runnable configuration (cubes, 512 x 512, SAMPLE 0..15): SHA-256
                      of the RGB float32 bytes of each single-SAMPLE image and of the 16-sample running mean
                      (results are compared bit for bit, so a digest is enough), and llvmpipe's wall time
@@ -34,7 +36,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(HERE, ".."))
-from conftest import constant_env, gradient_env, load_scene, textured_cubes  # noqa: E402
+from conftest import constant_env, gradient_env, load_scene, textured_cubes, tiny_cubes  # noqa: E402
 from gpuraytracer_amd.scene_io import write_rtscene  # noqa: E402
 from gpuraytracer_amd.camera import camera_matrix, DEFAULT_CLOCK  # noqa: E402
 from make_golden_vectors import ray_batch  # noqa: E402
@@ -74,13 +76,17 @@ def ref_func(shader, x, n_items, per_item, with_reference_text=False, env=None):
 def ref_hits(scene, o, d):
     n = len(o)
     np.concatenate([o, d], axis=1).astype(np.float32).tofile(tmp("rays.f32"))
-    run("hits", scene_path(scene), tmp("rays.f32"), n, tmp("hits.bin"))
+    run("hits", scene if os.path.sep in scene else scene_path(scene), tmp("rays.f32"), n, tmp("hits.bin"))
     raw = np.fromfile(tmp("hits.bin"), dtype=np.uint8)
     return raw[:4 * n].view(np.int32).copy(), raw[4 * n:].view(np.float32).reshape(n, 3).copy()
 
 
-def ref_image(scene, env, width, height, clock, recursion, first, count, cam, atlas=None):
+def ref_image(scene, env, width, height, clock, recursion, first, count, cam, atlas=None, exposure=None):
     """scene: name of a bundled scene or path of an rtscene file; atlas: path of an atlas description."""
+    if exposure is None:
+        os.environ.pop("REF_EXPOSURE", None)
+    else:
+        os.environ["REF_EXPOSURE"] = repr(float(exposure))
     np.ascontiguousarray(env, dtype=np.float32).tofile(tmp("env.f32"))
     np.ascontiguousarray(cam, dtype=np.float32).tofile(tmp("cam.f32"))
     args = ["image", scene if os.path.sep in scene else scene_path(scene), tmp("env.f32"), env.shape[1], env.shape[0],
@@ -131,6 +137,55 @@ IMAGE_CASES = [
     ("obiwan", "_ObiWan", constant_env(), 64, 64, 16, None, (0, 1)),
     ("obiwan_close", "_ObiWan", gradient_env(), 48, 48, 16, ((0.0, 1.0, -1.5), (-0.5, 0.0)), (0, 3)),
 ]
+
+
+def ref_write_tiny(path, scale):
+    write_rtscene(path, *tiny_cubes(scale))
+
+
+def make_extra():
+    """Cases added after the first set (kept apart so that the first set's files need not be rewritten):
+      ref_image_cubes_exposure.npz       EXPOSURE = 0.5 (Scene.cpp:331 always sets 1.0; the uniform scales the environment)
+      ref_image_cubes_textured_edge.npz  a 128^2 atlas whose albedo layer carries values at the edges of the
+                                         R11F_G11F_B10F upload conversion
+      ref_hits_tiny.npz                  findIntersection on the cubes scene scaled by 2^-66, where the triangle normals
+                                         (products of two edges) are denormal numbers: llvmpipe runs with denormals
+                                         flushed to zero, so every plane test sees a zero normal"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    os.makedirs(TMP, exist_ok=True)
+    cam = camera_matrix()
+    env = gradient_env()
+    out = {"env": env, "camera": cam, "clock": np.uint32(DEFAULT_CLOCK), "recursion": np.int32(6), "exposure": np.float32(0.5),
+           "samples": np.array([0, 5], dtype=np.uint32), "scene": np.array("cubes")}
+    for s in (0, 5):
+        out["sample_%d" % s] = ref_image("cubes", env, 64, 64, DEFAULT_CLOCK, 6, s, 1, cam, exposure=0.5)
+    np.savez_compressed(os.path.join(HERE, "ref_image_cubes_exposure.npz"), **out)
+    print("image cubes_exposure          64x64 RECURSION 6 SAMPLE [0, 5] EXPOSURE 0.5")
+
+    scene, layers, flags = textured_cubes(128, edge_texels=True)
+    write_rtscene(tmp("textured.rtscene"), *scene)
+    write_atlas(tmp("atlas.bin"), 128, [(2, k, layers[k]) for k in (0, 1, 2)], flags)
+    out = {"env": env, "camera": cam, "clock": np.uint32(777), "recursion": np.int32(6),
+           "samples": np.array([0, 1], dtype=np.uint32), "atlas_size": np.uint32(128)}
+    for s in (0, 1):
+        out["sample_%d" % s] = ref_image(tmp("textured.rtscene"), env, 48, 32, 777, 6, s, 1, cam, atlas=tmp("atlas.bin"))
+    np.savez_compressed(os.path.join(HERE, "ref_image_cubes_textured_edge.npz"), **out)
+    print("image cubes_textured_edge     48x32 RECURSION 6 SAMPLE [0, 1] atlas 128")
+
+    models, shadings, lights, materials = load_scene("cubes")
+    o0, d = ray_batch(models)
+    out = {"d": d, "scales": np.array([2.0 ** -42, 2.0 ** -44], dtype=np.float32)}
+    for k, scale in enumerate(out["scales"]):
+        # the plane distance dot(normal, origin - corner) is of the order scale^3: around 2^-126, the smallest normal number,
+        # for the first scale (some flushed, some not) and below it for the second
+        o = (o0 * scale).astype(np.float32)
+        ref_write_tiny(tmp("tiny.rtscene"), scale)
+        ids, uvt = ref_hits(tmp("tiny.rtscene"), o, d)
+        out["o_%d" % k], out["ids_%d" % k], out["uvt_%d" % k] = o, ids, uvt
+        print("hits tiny (scale 2^%d)  %d of %d rays hit" % (int(np.log2(scale)), int((ids >= 0).sum()), len(ids)))
+    np.savez_compressed(os.path.join(HERE, "ref_hits_tiny.npz"), **out)
+    for f in os.listdir(TMP):
+        os.remove(os.path.join(TMP, f))
 
 
 def main():
@@ -231,5 +286,7 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:] == ["irradiance"]:
         make_irradiance()
+    elif sys.argv[1:] == ["extra"]:
+        make_extra()
     else:
         main()

@@ -118,7 +118,7 @@ def test_hierarchy_equals_index_order_loop(gpu_ctx, name):
     assert (ids0 >= 0).mean() > 0.3
 
 
-REF_IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close"]
+REF_IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close", "cubes_exposure"]
 
 
 @pytest.mark.parametrize("pipeline", FORMS)
@@ -134,7 +134,7 @@ def test_images_equal_reference_shader(gpu_ctx, case, pipeline):
         want = g["sample_%d" % s]
         h, w = want.shape[:2]
         colour, _ = _render(gpu_ctx, w, h, s, 1, recursion=int(g["recursion"]), clock=int(g["clock"]),
-                            pipeline=pipeline, cam=g["camera"])
+                            pipeline=pipeline, cam=g["camera"], exposure=float(g["exposure"]) if "exposure" in g else 1.0)
         got = colour
         if s > 0:
             inv = np.float32(1.0) / np.float32(s + 1)
@@ -383,12 +383,14 @@ def test_launch_chaining_and_sample_split(gpu_ctx, cubes):
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
 
 
-def test_textured_materials_bit_exact(gpu_ctx, oracle_mod):
-    # synthetic albedo / normal / ARM layers on one material, small atlas: against the images of the reference's
-    # shader (single SAMPLE values) and against the checker (4-sample sums and counters)
-    g = np.load(os.path.join(GOLDEN, "ref_image_cubes_textured.npz"))
+@pytest.mark.parametrize("case", ["cubes_textured", "cubes_textured_edge"])
+def test_textured_materials_bit_exact(gpu_ctx, oracle_mod, case):
+    # synthetic albedo / normal / ARM layers on one material: against the images of the reference's shader (single
+    # SAMPLE values) and against the checker (4-sample sums and counters).  First case: 32^2 atlas; second: 128^2 atlas
+    # whose albedo texels include the edge values of the packed-float upload conversion (k_pack_atlas on the device)
+    g = np.load(os.path.join(GOLDEN, "ref_image_%s.npz" % case))
     S = int(g["atlas_size"])
-    (models, shadings, lights, materials), layers, flags = textured_cubes(S)
+    (models, shadings, lights, materials), layers, flags = textured_cubes(S, edge_texels=case.endswith("edge"))
     gpu_ctx.upload_scene(models, shadings, lights, materials)
     gpu_ctx.upload_env(g["env"])
     gpu_ctx.set_atlas_size(S)
@@ -415,6 +417,50 @@ def test_textured_materials_bit_exact(gpu_ctx, oracle_mod):
             same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
             assert same.all(), (pipeline, s)
     gpu_ctx.set_atlas_size(4096)
+
+
+def test_nonfinite_and_edge_texels_bit_exact(gpu_ctx, oracle_mod):
+    # the device's upload conversion (k_pack_atlas) on Inf / NaN / negative / tiny / huge texels, seen through whole
+    # images: the checker's conversion is pinned to the GL implementation's by its own test (ref_builtins.npz: pack_x)
+    S = 64
+    (models, shadings, lights, materials), layers, flags = textured_cubes(S, edge_texels=True, nonfinite_texels=True)
+    env = gradient_env()
+    gpu_ctx.upload_scene(models, shadings, lights, materials)
+    gpu_ctx.upload_env(env)
+    gpu_ctx.set_atlas_size(S)
+    sc = oracle_mod.OracleScene(models, shadings, lights, materials)
+    sc.upload_env(env)
+    sc.set_atlas_size(S)
+    for target in (gpu_ctx, sc):
+        for k in (0, 1, 2):
+            target.upload_atlas_layer(2, k, layers[k])
+        target.set_has_texture(flags)
+    want, wst = sc.render(CAM, 31337, 6, 1.0, 64, 48, 0, 6)
+    assert (~np.isfinite(want)).any() and np.isfinite(want).any()
+    for pipeline in (1, 3):
+        img, st = _render(gpu_ctx, 64, 48, 0, 6, clock=31337, pipeline=pipeline)
+        same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
+        assert same.all(), (pipeline, int((~same).sum()))
+        assert st["rays"] == wst["rays"]
+    gpu_ctx.set_atlas_size(4096)
+
+
+@pytest.mark.parametrize("accel", [0, -1])
+def test_denormal_numbers_are_kept_like_llvmpipe(gpu_ctx, accel):
+    # the reference's findIntersection under llvmpipe on the cubes scene scaled by 2^-42 and 2^-44: the plane distances
+    # are denormal numbers there, and the hits it reports are those of arithmetic that keeps them.  The products of the
+    # reference's depth comparison (raytracer.glsl:150) underflow to zero at this scale, so that the later index wins
+    # whatever the depths: the library's automatic choice (accel -1) keeps to the loop over all triangles for scenes
+    # with normals this small; the hierarchy forced on them (accel 1) prunes by depth and is not expected to agree.
+    from conftest import tiny_cubes
+    g = np.load(os.path.join(GOLDEN, "ref_hits_tiny.npz"))
+    for k, scale in enumerate(g["scales"]):
+        _upload(gpu_ctx, tiny_cubes(scale), constant_env())
+        gpu_ctx.set_option("accel", accel)
+        ids, uvt = gpu_ctx.closest_hit_batch(g["o_%d" % k], g["d"])
+        assert np.array_equal(ids, g["ids_%d" % k]), int((ids != g["ids_%d" % k]).sum())
+        hit = ids >= 0
+        assert np.array_equal(uvt[hit].view(np.uint32), g["uvt_%d" % k][hit].view(np.uint32))
 
 
 def _write_soup(base, seed, n_tris):
@@ -525,6 +571,12 @@ def test_error_behaviour(oracle_mod, cubes):
         bad["material_id"] = 9
         with pytest.raises(g.GpuRtError):       # material id out of range
             ctx.upload_scene(models[:4], bad, 0, materials)
+        # 2^28 triangles and more are refused before any record is read (the leaf links of the hierarchy hold 28 bits
+        # of slot number): the call goes straight through the C ABI with the small arrays' pointers
+        import ctypes
+        rc = ctx.lib.rt_upload_scene(ctx.h, models.ctypes.data_as(ctypes.c_void_p), shadings.ctypes.data_as(ctypes.c_void_p),
+                                     1 << 28, 0, materials.ctypes.data_as(ctypes.c_void_p), len(materials))
+        assert rc == -5, rc                     # RT_ERR_LIMIT
         ctx.upload_scene(models, shadings, lights, materials)
         with pytest.raises(g.GpuRtError):       # no frame / no target
             ctx.trace(0, 1, 1)

@@ -12,7 +12,7 @@ import pytest
 
 from conftest import GOLDEN, load_scene
 
-IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close"]
+IMAGE_CASES = ["cubes", "cubes_wide", "cubes_gradient", "sphere_gradient_npot", "box", "obiwan", "obiwan_close", "cubes_exposure"]
 
 
 def same_bits(a, b):
@@ -64,15 +64,16 @@ def test_images_equal_reference_shader(oracle_mod, case):
     sc = oracle_mod.OracleScene(models, shadings, lights, materials)
     sc.upload_env(g["env"])
     cam, clock, recursion = g["camera"], int(g["clock"]), int(g["recursion"])
+    exposure = float(g["exposure"]) if "exposure" in g else 1.0       # EXPOSURE uniform (raytracer.glsl:47, :275)
     for s in g["samples"].tolist():
         want = g["sample_%d" % s]
         h, w = want.shape[:2]
-        colour, _ = sc.render(cam, clock, recursion, 1.0, w, h, s, 1)
+        colour, _ = sc.render(cam, clock, recursion, exposure, w, h, s, 1)
         got = expected_from_reference_colour(colour, s)
         ok = same_bits(got, want).all(axis=2)
         assert ok.all(), "%s SAMPLE %d: %d of %d pixels differ" % (case, s, int((~ok).sum()), ok.size)
         # the checker's own running-mean mode does the same arithmetic
-        mean, _ = sc.render(cam, clock, recursion, 1.0, w, h, s, 1, mode="mean")
+        mean, _ = sc.render(cam, clock, recursion, exposure, w, h, s, 1, mode="mean")
         assert same_bits(mean, want).all()
 
 
@@ -132,11 +133,14 @@ def test_irradiance_prefilter_equals_reference_shader(oracle_mod):
     assert np.allclose(other, g["irr1"], rtol=1e-5, atol=0)
 
 
-def test_textured_images_equal_reference_shader(oracle_mod):
-    # atlas path: texture coordinates, tangent frame, normal map, ARM layer, 11/11/10-bit texels
+@pytest.mark.parametrize("case", ["cubes_textured", "cubes_textured_edge"])
+def test_textured_images_equal_reference_shader(oracle_mod, case):
+    # atlas path: texture coordinates, tangent frame, normal map, ARM layer, 11/11/10-bit texels; the second case has
+    # a 128^2 atlas whose albedo texels include the edge values of the packed-float upload (negative, below the
+    # smallest packed number, above the largest)
     from conftest import textured_cubes
-    g = np.load(os.path.join(GOLDEN, "ref_image_cubes_textured.npz"))
-    scene, layers, flags = textured_cubes(int(g["atlas_size"]))
+    g = np.load(os.path.join(GOLDEN, "ref_image_%s.npz" % case))
+    scene, layers, flags = textured_cubes(int(g["atlas_size"]), edge_texels=case.endswith("edge"))
     sc = oracle_mod.OracleScene(*scene)
     sc.upload_env(g["env"])
     sc.set_atlas_size(int(g["atlas_size"]))
@@ -148,3 +152,25 @@ def test_textured_images_equal_reference_shader(oracle_mod):
         h, w = want.shape[:2]
         mean, _ = sc.render(g["camera"], int(g["clock"]), int(g["recursion"]), 1.0, w, h, s, 1, mode="mean")
         assert same_bits(mean, want).all(), s
+
+
+def test_denormal_numbers_are_kept_like_llvmpipe(oracle_mod):
+    """findIntersection of the reference under llvmpipe on the cubes scene scaled by 2^-42 and 2^-44, where the plane
+    distances dot(normal, origin - corner) are denormal numbers: the hits the reference reports are those of
+    arithmetic that keeps denormals (with inputs and results flushed to zero part of the rays would miss)."""
+    from conftest import tiny_cubes
+    g = np.load(os.path.join(GOLDEN, "ref_hits_tiny.npz"))
+    for k, scale in enumerate(g["scales"]):
+        sc = oracle_mod.OracleScene(*tiny_cubes(scale))
+        o, d = g["o_%d" % k], g["d"]
+        ids, uvt = sc.closest_hit_batch(o, d)
+        assert np.array_equal(ids, g["ids_%d" % k])
+        hit = ids >= 0
+        assert hit.sum() > 3000
+        assert same_bits(uvt[hit], g["uvt_%d" % k][hit]).all()
+        try:
+            oracle_mod.set_flush_denormals(True)
+            flushed, _ = sc.closest_hit_batch(o, d)
+        finally:
+            oracle_mod.set_flush_denormals(False)
+        assert (flushed != ids).sum() > 0, "the case does not reach the denormal range"
