@@ -80,10 +80,28 @@ RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
 #ifndef RT_XCD_ORDER
 #define RT_XCD_ORDER 1
 #endif
-#ifndef RT_TILE_MAJOR
-#define RT_TILE_MAJOR 1
+#ifndef RT_DYNAMIC_CHUNKS
+#define RT_DYNAMIC_CHUNKS 1
 #endif
+
 constexpr uint32_t N_XCD = 8;
+#ifndef RT_RUNS_PER_XCD
+#define RT_RUNS_PER_XCD 4
+#endif
+#ifndef RT_CHUNK_BLOCK
+#define RT_CHUNK_BLOCK 64
+#endif
+#ifndef RT_DYNAMIC_SHARE
+#define RT_DYNAMIC_SHARE 4
+#endif
+constexpr uint32_t RUNS_PER_XCD = RT_RUNS_PER_XCD, N_RUNS = N_XCD * RUNS_PER_XCD;
+constexpr uint32_t CHUNK_BLOCK = RT_CHUNK_BLOCK;        // consecutive chunks that stay in one run (one tile's samples at 64 per pass)
+constexpr uint32_t DYNAMIC_SHARE = RT_DYNAMIC_SHARE;    // 1/DYNAMIC_SHARE of the rounds is handed out as waves become free
+// The run a wave works on as its `part`-th: its own, then the others of its XCD, then those of the other XCDs.
+RT_DEV uint32_t run_of_part(uint32_t home, uint32_t part) {
+    const uint32_t xcd = home / RUNS_PER_XCD, sub = home % RUNS_PER_XCD;
+    return ((xcd + part / RUNS_PER_XCD) % N_XCD) * RUNS_PER_XCD + (sub + part) % RUNS_PER_XCD;
+}
 static_assert((PIPE_WAVES / WG_WAVES) % N_XCD == 0, "workgroups divide evenly among the XCDs");
 RT_DEV uint32_t first_chunk_of_wave() {
     if (!RT_XCD_ORDER) return wave_index();
@@ -224,6 +242,7 @@ struct PipeBuffers {
     uint4 *pd;
     float4 *h0, *energy, *kd, *ks;
     uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
+    uint32_t *work;                             // [N_RUNS] chunks of the depth-0 kernel handed out so far, per part of the target
     uint32_t region_cap;
     unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
 };
@@ -427,23 +446,77 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     // that the waves at work at the same time are on few tiles: the nodes and triangles under a tile are fetched once
     // and then found in the caches by the tile's other samples (slot-major order meets a tile again only after the whole
     // image, i.e. after the whole scene, has gone through the caches).
-    const uint32_t n_chunks = (paths_per_sample >> 6) * tab.n;
-    for (uint32_t chunk = first_chunk_of_wave(); chunk < n_chunks; chunk += (uint32_t)PIPE_WAVES) {
+    const uint32_t n_tiles = paths_per_sample >> 6;
+    const uint32_t n_chunks = n_tiles * tab.n;
+    // Who renders which chunk.  Most of the pass is dealt out in fixed shares: in round r the waves take the chunks
+    // r * PIPE_WAVES ... in the XCD-aware order of first_chunk_of_wave(), so that every wave, and with it every queue
+    // region, gets the same number of chunks from all over the image (the deeper stages work region by region and
+    // take as long as their fullest region).  But chunks differ a lot in cost (sky, surfaces, lights), and with fixed
+    // shares alone a fifth of the wave slots stood empty while the slowest waves finished (SQ_WAVE_CYCLES against waves
+    // x kernel time).  So the last quarter of the rounds is handed out chunk by chunk as waves become free, through
+    // N_RUNS counters (b.work; one counter sustains about ten million atomic operations a second, they are carried
+    // out beyond the XCDs' own L2s): run x holds the blocks x, x + N_RUNS, ... of CHUNK_BLOCK consecutive chunks of
+    // that part; a wave starts on a run of its own XCD and goes on to the others when it is used up.  Which wave renders
+    // a chunk only decides in which queue region its survivors wait, the image does not depend on it.  The counter
+    // value for the next chunk is fetched while the current chunk is rendered.
+    const uint32_t n_rounds = (n_chunks + (uint32_t)PIPE_WAVES - 1u) / (uint32_t)PIPE_WAVES;
+    const uint32_t fixed_rounds = RT_DYNAMIC_CHUNKS ? n_rounds - n_rounds / DYNAMIC_SHARE : n_rounds;
+    const uint32_t fixed_chunks = fixed_rounds * (uint32_t)PIPE_WAVES;          // may exceed n_chunks when nothing is left
+    const uint32_t n_blocks = n_chunks > fixed_chunks ? (n_chunks - fixed_chunks + CHUNK_BLOCK - 1u) / CHUNK_BLOCK : 0u;
+    const uint32_t home = (blockIdx.x % N_XCD) * RUNS_PER_XCD + (blockIdx.x / N_XCD) % RUNS_PER_XCD;
+    const uint32_t first = first_chunk_of_wave();
+    uint32_t round = 0, part = 0, run_x = home, run_count = 0, ahead = 0;
+    bool have_ahead = false;
+    auto enter_part = [&]() {
+        run_x = run_of_part(home, part);
+        run_count = n_blocks > run_x ? ((n_blocks - run_x + N_RUNS - 1u) / N_RUNS) * CHUNK_BLOCK : 0u;
+    };
+    auto take = [&]() -> uint32_t {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(&b.work[run_x], 1u);
+        return c;
+    };
+    enter_part();
+    for (;;) {
+        uint32_t chunk;
+        if (round < fixed_rounds) {
+            chunk = round * (uint32_t)PIPE_WAVES + first;
+            round++;
+        } else {
+            uint32_t c;
+            if (have_ahead) {
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
+            } else {
+                if (fill_next + 64u > b.region_cap) break;        // this wave's region cannot take another chunk whole
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)take());
+            }
+            have_ahead = false;
+            if (c >= run_count) {
+                if (++part == N_RUNS) break;
+                enter_part();
+                continue;
+            }
+            // the next one is asked for now if the region holds this chunk and the next whatever survives
+            have_ahead = fill_next + 128u <= b.region_cap;
+            if (have_ahead) ahead = take();
+            const uint32_t block_in_run = c / CHUNK_BLOCK;
+            chunk = fixed_chunks + (block_in_run * N_RUNS + run_x) * CHUNK_BLOCK + (c - block_in_run * CHUNK_BLOCK);
+        }
+        if (chunk >= n_chunks) continue;
 #if RT_SECTION_CLOCKS > 0
         unsigned long long mark_ = __builtin_amdgcn_s_memtime();
 #endif
-        // slot, SAMPLE and the coin are the same for the whole wave
-#if RT_TILE_MAJOR
-        // (the slot is rotated by the round: a wave whose chunks all had the same slot, as happens when the pass size
+        // A chunk is one tile of one sample: slot, SAMPLE and the coin are the same for the whole wave.  Chunks are numbered
+        // tile-major (all samples of a tile follow each other), so that the waves at work at the same time are on few
+        // tiles: the nodes and triangles under a tile are fetched once and then found in the caches by the tile's other
+        // samples (slot-major order meets a tile again only after the whole image, i.e. the whole scene, has gone through
+        // the caches).  The slot is rotated by the round, by an amount that depends on the tile alone so that the chunks of
+        // a tile still cover every slot once: a wave whose chunks all had the same slot, as happens when the pass size
         // divides the wave count, would draw the same coin for all its paths, and the probe stages of the next depths
-        // would find their work in half of the regions)
-        // (the amount depends on the tile alone, so that the chunks of a tile still cover every slot once)
+        // would find their work in half of the regions.
         const uint32_t tile_of_chunk = chunk / tab.n, first_of_tile = tile_of_chunk * tab.n;
         const uint32_t slot = (chunk - first_of_tile + first_of_tile / (uint32_t)PIPE_WAVES) % tab.n;
         const uint32_t base = slot * paths_per_sample + tile_of_chunk * 64u;
-#else
-        const uint32_t base = chunk * 64u, slot = base / paths_per_sample;
-#endif
         const uint32_t id = base + lane;
         PathState ps;
         const bool live = first_path(fr, tab.sample[slot], base - slot * paths_per_sample, tiles_x, id < total, ps);
@@ -915,7 +988,8 @@ struct Pipeline {
                 (void **)&buf.energy, (void **)&buf.kd, (void **)&buf.ks};
     }
     std::vector<void **> counter_buffers() {
-        return {(void **)&buf.wstats, (void **)&buf.n_ext[0], (void **)&buf.n_ext[1], (void **)&buf.n_shadow, (void **)&buf.n_glossy};
+        return {(void **)&buf.wstats, (void **)&buf.n_ext[0], (void **)&buf.n_ext[1], (void **)&buf.n_shadow, (void **)&buf.n_glossy,
+                (void **)&buf.work};
     }
 
     void free_paths() {
@@ -932,11 +1006,13 @@ struct Pipeline {
         buf = PipeBuffers{};
     }
 
-    // A wave can never emit more entries than it consumed, so ceil(chunks / PIPE_WAVES) * 64 entries per region suffice.
+    // From depth 1 on a wave can never emit more entries than it consumed.  The depth-0 kernel hands out its chunks
+    // as waves become free and a wave stops taking chunks when its region cannot hold another one whole, so with one
+    // chunk of slack per region, (ceil(chunks / PIPE_WAVES) + 1) * 64 entries, the regions that still have room can
+    // always hold what is left.
     static uint32_t region_cap_for(size_t paths) {
         const size_t chunks = (paths + 63) / 64;
-        const uint32_t cap = (uint32_t)(((chunks + PIPE_WAVES - 1) / PIPE_WAVES) * 64);
-        return cap < 64u ? 64u : cap;
+        return (uint32_t)(((chunks + PIPE_WAVES - 1) / PIPE_WAVES + 1) * 64);
     }
     // Device memory of the queues of a pass of `paths` pixel-samples.
     static size_t queue_bytes_for(size_t paths, bool with_h0) {
@@ -957,6 +1033,7 @@ struct Pipeline {
             PIPE_ALLOC(buf.n_ext[1], sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_shadow, sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_glossy, sizeof(uint32_t) * PIPE_WAVES);
+            PIPE_ALLOC(buf.work, sizeof(uint32_t) * N_RUNS);
         }
         if (paths > cap_paths || (need_h0 && !have_h0)) {
             const size_t want = paths > cap_paths ? paths : cap_paths;
@@ -1067,6 +1144,7 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
     };
     const dim3 grid(PIPE_WAVES / WG_WAVES), block(64 * WG_WAVES);
     // depth 0 runs its probes in place (k_first): queue 0 is never read and the first queue is 1
+    PIPE_TRY(hipMemsetAsync(buf.work, 0, sizeof(uint32_t) * N_RUNS, stream));
     PIPE_TRY(stamp(3));
     hipLaunchKernelGGL(k_first<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
     PIPE_TRY(hipGetLastError());
