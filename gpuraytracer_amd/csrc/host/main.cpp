@@ -2,10 +2,11 @@
 // scene, renders `spp` samples per pixel with the fixed camera of the reference's start-up state and
 // writes the mean image as OpenEXR, printing samples per second like finalRender (RayTracer.cpp:29-53).
 //
-//   gpuPT <model base path> <width> <height> [spp=64] [out.exr=final.exr] [env.exr]
+//   gpuPT <model base path> <width> <height> [spp=64] [out.exr=final.exr] [env.exr|-] [<material id>=<texture base> ...]
 //
-// Without an environment file a constant (0.5, 0.7, 1.0) sky is used (the reference's environment
-// textures are not part of its repository).
+// Without an environment file (or with "-") a constant (0.5, 0.7, 1.0) sky is used (the reference's environment
+// textures are not part of its repository).  "<id>=<base>" loads <base>_albedo.exr, <base>_normal.exr and
+// <base>_arm.exr into the atlas layers of material <id>, as the loadMaterial calls of RayTracer.cpp:161-162 do.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +18,7 @@
 
 int main(int argc, char *args[]) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <model base path> <width> <height> [spp] [out.exr] [env.exr]\n", args[0]);
+        fprintf(stderr, "usage: %s <model base path> <width> <height> [spp] [out.exr] [env.exr|-] [<material id>=<texture base> ...]\n", args[0]);
         return EXIT_FAILURE;
     }
     const std::string name(args[1]);
@@ -33,7 +34,15 @@ int main(int argc, char *args[]) {
         return 1;
     }
     bool env_ok = false;
-    if (argc > 6) env_ok = scene.loadEnvironmentTexture(args[6]);
+    if (argc > 6 && std::string(args[6]) != "-") env_ok = scene.loadEnvironmentTexture(args[6]);
+    for (int k = 7; k < argc; k++) {
+        const std::string spec(args[k]);
+        const size_t eq = spec.find('=');
+        if (eq == std::string::npos || eq == 0) { fprintf(stderr, "bad material argument %s\n", args[k]); return EXIT_FAILURE; }
+        const uint32_t id = (uint32_t)atoi(spec.substr(0, eq).c_str());
+        const bool textured = scene.loadMaterial(spec.substr(eq + 1), id);
+        std::cout << "Material " << id << (textured ? " textured" : " not textured") << '\n';
+    }
     if (!env_ok) {
         std::vector<float> env(8 * 4 * 4);
         for (int i = 0; i < 32; i++) { env[i * 4] = 0.5f; env[i * 4 + 1] = 0.7f; env[i * 4 + 2] = 1.0f; env[i * 4 + 3] = 1.0f; }

@@ -187,7 +187,9 @@ int rt_reset_stats(rt_context *ctx);
  *                   1 = staged kernels over compacted ray queues (default)
  *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 128; the queues of a pass
  *                   take about 290 bytes of device memory per pixel and sample, rt_stats.queue_bytes tells)
- *   "accel"         -1 = bounding-volume hierarchy for scenes of 64 triangles or more (default),
+ *   "accel"         -1 = bounding-volume hierarchy for scenes of 64 triangles or more (default; scenes with a triangle
+ *                   whose |cross(u, v)| is below 2^-40 keep the loops: the reference's depth comparison underflows
+ *                   there and the later index wins whatever the depths, which only the loops reproduce),
  *                   0 = the reference's loops over all triangles, 1 = hierarchy always
  *   "resident"      -1 = a hierarchy that fits (about 480 triangles, depth under 16) is staged into LDS whole, leaf
  *                   triangles included (default), 0 = only its first nodes are

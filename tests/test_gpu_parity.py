@@ -746,3 +746,40 @@ def test_host_program_renders_and_writes_exr(oracle_mod, tmp_path):
     # and the library's own reader agrees with the independent one
     back = host.read_exr(out)
     assert np.array_equal(back[..., :3].view(np.uint32), got.view(np.uint32))
+
+
+def test_host_program_loads_material_textures_from_exr(oracle_mod, tmp_path):
+    # Scene::loadMaterial of the C++ host (Scene.cpp:206-229 with loadTexture, :75-102): <base>_albedo.exr, _normal.exr
+    # and _arm.exr written by the library's EXR writer go through its reader into the corner of 4096^2 atlas layers
+    # (the reference's atlas size) of two materials of a textured height field; the rendered mean image against the checker
+    import subprocess
+    from conftest import ROOT
+    from gpuraytracer_amd import host, synthetic
+    base = str(tmp_path / "grid")
+    synthetic.write_displaced_grid(base, 24)
+    layers = synthetic.texture_layers(64)
+    tex = str(tmp_path / "tex")
+    for suffix, pixels in zip(("albedo", "normal", "arm"), layers):
+        host.write_exr("%s_%s.exr" % (tex, suffix), pixels[..., :3])
+    out = str(tmp_path / "final.exr")
+    exe = os.path.join(ROOT, "gpuraytracer_amd", "gpuPT")
+    res = subprocess.run([exe, base, "64", "48", "3", out, "-", "0=" + tex, "1=" + tex, "2=" + str(tmp_path / "missing")],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "Material 0 textured" in res.stdout and "Material 1 textured" in res.stdout and "Material 2 not textured" in res.stdout
+    scene = host.load_wavefront(base)
+    sc = oracle_mod.OracleScene(*scene)
+    sc.upload_env(constant_env())
+    sc.set_atlas_size(4096)
+    for m in (0, 1):
+        for k in range(3):
+            back = host.read_exr("%s_%s.exr" % (tex, ("albedo", "normal", "arm")[k]))
+            assert np.array_equal(back[..., :3], layers[k][..., :3])          # float32 pixels survive the file unchanged
+            sc.upload_atlas_layer(m, k, back)
+    sc.set_has_texture(np.array([1, 1, 0], np.int32))
+    want, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 64, 48, 0, 3)
+    mean = want * (np.float32(1.0) / np.float32(3.0))
+    planes, names, _ = _read_exr_uncompressed(out)
+    got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
+    same = (got.view(np.uint32) == mean.view(np.uint32)) | (np.isnan(got) & np.isnan(mean))
+    assert same.all(), int((~same).sum())
