@@ -16,7 +16,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_synchronize", "rt_upload_scene",
     "rt_set_atlas_size", "rt_upload_atlas_layer", "rt_set_has_texture", "rt_upload_env", "rt_prefilter_irradiance", "rt_resize",
     "rt_set_sum_buffer", "rt_set_frame", "rt_trace", "rt_read_sum", "rt_read_sum_static", "rt_closest_hit_batch",
-    "rt_closest_hit_batch_device", "rt_read_srgb8", "rt_get_stats", "rt_reset_stats", "rt_set_option",
+    "rt_closest_hit_batch_device", "rt_read_srgb8", "rt_get_stats", "rt_reset_stats", "rt_set_option", "rt_accumulate_from",
 ]
 
 
@@ -74,6 +74,7 @@ def load_library():
     lib.rt_trace.argtypes = [vp, c.c_uint32, c.c_uint32, c.c_uint32]
     lib.rt_read_sum.argtypes = [vp, vp, c.POINTER(c.c_uint64)]
     lib.rt_read_sum_static.argtypes = [vp, vp, c.POINTER(c.c_uint64)]
+    lib.rt_accumulate_from.argtypes = [vp, vp]
     lib.rt_closest_hit_batch.argtypes = [vp, vp, vp, c.c_uint64, vp, vp]
     lib.rt_closest_hit_batch_device.argtypes = [vp, vp, vp, c.c_uint64, vp, vp]
     lib.rt_read_srgb8.argtypes = [vp, vp]
@@ -189,6 +190,10 @@ class Context:
         n = ctypes.c_uint64()
         self._check(self.lib.rt_read_sum(self.h, _ptr(rgb), ctypes.byref(n)))
         return rgb, int(n.value)
+
+    def accumulate_from(self, other):
+        """Adds another context's sums and sample count to this one's (same target size; any GPU of the node)."""
+        self._check(self.lib.rt_accumulate_from(self.h, other.h))
 
     def read_sum_static(self):
         """read_sum through the library's built-in staging buffer (no device allocation)."""

@@ -266,6 +266,10 @@ uint64_t Scene::rays() {
     return st.rays;
 }
 
+bool Scene::addSumsOf(Scene &other) {
+    return m_ctx && other.m_ctx && rt_accumulate_from(m_ctx, other.m_ctx) == RT_OK;
+}
+
 bool Scene::exportEXR(const char *name) {
     if (!m_ctx || m_width == 0) return false;
     std::vector<float> rgb((size_t)m_width * m_height * 3);

@@ -48,6 +48,9 @@ public:
     bool prepare(int &width, int &height, bool moving, const float camera[16], uint32_t clock);   // Scene.cpp:435-464
     bool traceScene(uint32_t width, uint32_t height, uint32_t sample);  // Scene.cpp:423-433
     bool traceSamples(uint32_t sample_begin, uint32_t sample_count, uint32_t stride = 1);
+    // Adds what `other` (same scene and target on this or another GPU) has rendered to this scene's sums; the reference
+    // has one GPU and no counterpart.
+    bool addSumsOf(Scene &other);
     bool exportEXR(const char *name);                                   // Scene.cpp:496-509 (row 0 = TEXEL.y 0)
     bool exportPNG8(const char *name);                                  // sRGB transfer of displayQuad.fs:19-34, binary PPM
     uint64_t rays();

@@ -246,6 +246,15 @@ __global__ void k_pack_atlas(const float4 *__restrict__ src, uint32_t w, uint32_
     dst[(size_t)y * size + x] = encode_ufloat(p.x, 6) | (encode_ufloat(p.y, 6) << 11) | (encode_ufloat(p.z, 5) << 22);
 }
 
+__global__ void k_add_sums(float4 *__restrict__ sum, const float4 *__restrict__ other, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = sum[i];
+    const float4 o = other[i];
+    s.x += o.x; s.y += o.y; s.z += o.z;
+    sum[i] = s;
+}
+
 __global__ void k_sum_to_rgb(const float4 *__restrict__ sum, unsigned long long n, float *__restrict__ rgb) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -527,6 +536,33 @@ int rt_set_sum_buffer(rt_context *ctx, float *device_rgba) {
             HIP_TRY(ctx, hipMalloc(&ctx->d_sum_own, sizeof(float4) * (size_t)ctx->width * ctx->height));
         ctx->d_sum = ctx->d_sum_own;
     }
+    return RT_OK;
+}
+
+int rt_accumulate_from(rt_context *ctx, rt_context *other) {
+    if (!ctx || !other || ctx == other) return RT_ERR_INVALID;
+    if (ctx->width == 0 || !ctx->d_sum || !other->d_sum) return fail(ctx, RT_ERR_STATE, "rt_accumulate_from: no target (rt_resize)");
+    if (ctx->width != other->width || ctx->height != other->height)
+        return fail(ctx, RT_ERR_INVALID, "rt_accumulate_from: targets differ (%ux%u, %ux%u)", ctx->width, ctx->height,
+                    other->width, other->height);
+    const unsigned long long n = (unsigned long long)ctx->width * ctx->height;
+    if (bind_device(other)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipStreamSynchronize(other->stream));
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    const float4 *src = other->d_sum;
+    float4 *staging = nullptr;
+    if (other->device != ctx->device) {
+        HIP_TRY(ctx, hipMalloc(&staging, sizeof(float4) * n));
+        const hipError_t e = hipMemcpyPeerAsync(staging, ctx->device, other->d_sum, other->device, sizeof(float4) * n, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(staging); return fail(ctx, RT_ERR_DEVICE, "rt_accumulate_from: %s", hipGetErrorString(e)); }
+        src = staging;
+    }
+    hipLaunchKernelGGL(k_add_sums, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_sum, src, n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (staging) (void)hipFree(staging);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "rt_accumulate_from: %s", hipGetErrorString(e));
+    ctx->n_samples += other->n_samples;
     return RT_OK;
 }
 

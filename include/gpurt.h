@@ -140,6 +140,14 @@ int rt_resize(rt_context *ctx, uint32_t width, uint32_t height);
  * host keep the buffer in a tensor it can hand to a collective. */
 int rt_set_sum_buffer(rt_context *ctx, float *device_rgba);
 
+/* No counterpart in the reference (it renders on one GPU): adds the sums `other` has accumulated, and its sample count,
+ * to those of `ctx`.  Both must have the same target size; `other` may live on another GPU (its sums then travel over
+ * the peer link, xGMI between the GPUs of one node, through a staging buffer this call allocates and frees).  Waits for
+ * `other`'s stream, enqueues the addition on `ctx`'s and returns when it is done.  For hosts that drive several GPUs
+ * from one process: context r of N renders SAMPLE = r + k * N (rt_trace(r, count, N)), then context 0 adds the
+ * others in ascending order, which fixes the association of the float sums. */
+int rt_accumulate_from(rt_context *ctx, rt_context *other);
+
 /* Scene::prepare (Scene.cpp:435-464): CAMERA (16 floats, column-major),
  * CLOCK, RECURSION, and the EXPOSURE uniform set at Scene.cpp:331. */
 int rt_set_frame(rt_context *ctx, const float camera[16], uint32_t clock,

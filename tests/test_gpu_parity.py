@@ -783,3 +783,58 @@ def test_host_program_loads_material_textures_from_exr(oracle_mod, tmp_path):
     got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
     same = (got.view(np.uint32) == mean.view(np.uint32)) | (np.isnan(got) & np.isnan(mean))
     assert same.all(), int((~same).sum())
+
+
+def test_several_contexts_in_one_process_add_up(oracle_mod, cubes, tmp_path):
+    # One host process driving several GPUs (here: three contexts on the one GPU of the test machine): context r of N
+    # renders SAMPLE = r + k * N, context 0 then adds the others with rt_accumulate_from in ascending order.  The checker
+    # reproduces exactly that association of the sums.  Then the same through the C++ host program (--devices=0,0).
+    import subprocess
+    import gpuraytracer_amd as g
+    from conftest import ROOT
+    from gpuraytracer_amd import host
+    from gpuraytracer_amd.distributed import shard_samples
+    W, H, SPP, N = 40, 24, 7, 3
+    ctxs = [g.Context(0) for _ in range(N)]
+    try:
+        for r, ctx in enumerate(ctxs):
+            _upload(ctx, cubes, constant_env())
+            ctx.resize(W, H)
+            ctx.set_frame(CAM, DEFAULT_CLOCK, 6, 1.0)
+            begin, count, stride = shard_samples(SPP, r, N)
+            ctx.trace(begin, count, stride)
+        for other in ctxs[1:]:
+            ctxs[0].accumulate_from(other)
+        with pytest.raises(g.GpuRtError):
+            ctxs[1].resize(W + 8, H)
+            ctxs[0].accumulate_from(ctxs[1])                   # targets differ
+        got, n = ctxs[0].read_sum()
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+    assert n == SPP
+    sc = oracle_mod.OracleScene(*cubes)
+    sc.upload_env(constant_env())
+    want = None
+    for r in range(N):
+        part, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, W, H, *shard_samples(SPP, r, N))
+        want = part if want is None else (want + part).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+    base = str(tmp_path / "soup")
+    _write_soup(base, 3, 300)
+    out = str(tmp_path / "two.exr")
+    exe = os.path.join(ROOT, "gpuraytracer_amd", "gpuPT")
+    res = subprocess.run([exe, "--devices=0,0", base, "40", "24", "5", out], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "on 2 GPUs" in res.stdout
+    scene = host.load_wavefront(base)
+    sc = oracle_mod.OracleScene(*scene)
+    sc.upload_env(constant_env())
+    a, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 40, 24, 0, 3, 2)
+    b, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 40, 24, 1, 2, 2)
+    mean = (a + b).astype(np.float32) * (np.float32(1.0) / np.float32(5.0))
+    planes, names, _ = _read_exr_uncompressed(out)
+    got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
+    same = (got.view(np.uint32) == mean.view(np.uint32)) | (np.isnan(got) & np.isnan(mean))
+    assert same.all(), int((~same).sum())
