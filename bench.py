@@ -315,6 +315,18 @@ def main():
                     "bytes_per_launch": algo / ext_n,
                     "note": "bound by vector instruction issue and the latency of dependent LDS accesses, not by "
                             "bandwidth: see valu_issue"}
+            if comparable and ext_ms > 0 and "TCC_HIT_sum" in prof:
+                # what the same counter passes say about the memory path during a launch: bytes that crossed the fabric side
+                # of the L2s (HBM or Infinity Cache) per second, the L2 hit rate, and how busy the CUs' vector memory
+                # front ends (texture addressers) were; hierarchies that do not fit LDS/L2 are bound there
+                launch_s = ext_ms / ext_n * 1e-3
+                roof["memory_path"] = {
+                    "beyond_l2_GBps": roof["traffic"] / launch_s / 1e9,
+                    "beyond_l2_frac_of_hbm_peak": roof["traffic"] / launch_s / 1e9 / 8000.0,
+                    "l2_requests_per_launch": prof["TCC_HIT_sum"] + prof["TCC_MISS_sum"],
+                    "l2_hit_rate": prof["TCC_HIT_sum"] / max(1.0, prof["TCC_HIT_sum"] + prof["TCC_MISS_sum"]),
+                    "vector_memory_busy_frac": prof.get("TA_BUSY_avr", 0.0) / max(1.0, prof.get("gpu_cycles", 0.0)) or None,
+                    "source": provenance}
             if comparable and ext_ms > 0:
                 # vector instructions of one launch (counter pass) over the live launch time, against the issue rate a
                 # SIMD sustains (profiles/r02_valu_ceiling.txt)

@@ -16,7 +16,13 @@ except OSError:
     command = "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bruteforce-pass"
 out = ["# rocprofv3 summary '%s': %s\n# (3 passes of 64 spp each at 1920x1080 unless the command says otherwise: 3 launches of "
        "the depth-0 kernel)\n" % (tag, command)]
-rows = list(csv.DictReader(open(glob.glob(base + "/trace/*/*_kernel_stats.csv")[0])))
+def newest(pattern):
+    """gpurun merges every run's files into the same directories: take the latest."""
+    files = glob.glob(pattern)
+    return max(files, key=os.path.getmtime) if files else None
+
+
+rows = list(csv.DictReader(open(newest(base + "/trace/*/*_kernel_stats.csv"))))
 out.append("\n## kernel stats (--kernel-trace --stats)\n%-60s %6s %14s %12s %7s\n" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
 for r in rows:
     if "rt::" in r["Name"]:
@@ -26,8 +32,8 @@ out.append("\n## PMC passes (separate runs; average per launch; FETCH_SIZE / WRI
            "## on gfx950 FETCH_SIZE counts 64 bytes for every 128-byte read, so wide reads are to be doubled)\n")
 per_kernel = collections.defaultdict(dict)
 for d in sorted(glob.glob(base + "/pmc_*")):
-    f = glob.glob(d + "/*/*_counter_collection.csv")
-    if not f:
+    f = [newest(d + "/*/*_counter_collection.csv")]
+    if not f[0]:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
