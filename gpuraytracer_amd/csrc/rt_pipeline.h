@@ -279,6 +279,81 @@ RT_DEV void finish_path(const PipeBuffers &b, uint32_t id, const PathState &ps) 
     b.energy[id] = make_float4(ps.energy.x, ps.energy.y, ps.energy.z, 0.0f);
 }
 
+// Even shares of a queue for the tail kernel.  A stage reads what the stage before left in the 4096 regions, and
+// regions fill unevenly (a wave whose tiles show the object leaves many survivors, one that saw sky none): a wave that
+// reads its own region only takes as long as that region is full, and the kernel as long as its fullest one (wave
+// slots in use during the tail kernel of a RECURSION 16 pass: 32 %).  The records of all regions, taken in region order,
+// form one sequence; wave w reads the w-th of 4096 equal slices of it, wherever its records lie.  The tail kernel
+// writes no queue, so nothing else changes (_ObiWan RECURSION 16: +3.6 %).  The extend stage could read its input the
+// same way (a wave still writes to its own regions, and never more than it read) but measured slower with it, cubes
+// -2 %, _ObiWan -1 %; a probe stage may not: it adds to the region the extend stage of the same depth has already
+// written to, and must stay with the records that stage counted for it.
+struct SliceCursor { uint32_t region, offset, left, count; };      // wave-uniform; count = fill of `region`
+static_assert(PIPE_WAVES == 64 * 64, "slice_begin sums the fill counts as 64 lanes x 64 regions");
+
+RT_DEV uint32_t wave_scan_inclusive(uint32_t v) {
+    const uint32_t lane = lane_index();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= (uint32_t)off) v += up;
+    }
+    return v;
+}
+// The slice of wave_index() in the sequence of all records of a queue whose fill counts are counts[PIPE_WAVES].
+RT_DEV SliceCursor slice_begin(const uint32_t *__restrict__ counts) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    const uint4 *mine = (const uint4 *)(counts + lane * 64u);
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const uint4 c = mine[j]; s += (c.x + c.y) + (c.z + c.w); }
+    const uint32_t inc = wave_scan_inclusive(s);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    const uint32_t a = (uint32_t)((unsigned long long)total * wave / (uint32_t)PIPE_WAVES);
+    const uint32_t e = (uint32_t)((unsigned long long)total * (wave + 1u) / (uint32_t)PIPE_WAVES);
+    SliceCursor c;
+    c.region = 0; c.offset = 0; c.count = 0; c.left = e - a;
+    if (c.left == 0) return c;
+    // the lane whose 64 regions hold record a, then the region among them
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(a < inc);
+    const uint32_t l1 = (uint32_t)__builtin_ctzll(m1);
+    const uint32_t before1 = (uint32_t)__shfl((int)(inc - s), (int)l1, 64);
+    const uint32_t s2 = counts[l1 * 64u + lane];
+    const uint32_t inc2 = wave_scan_inclusive(s2);
+    const uint32_t a2 = a - before1;
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(a2 < inc2);
+    const uint32_t l2 = (uint32_t)__builtin_ctzll(m2);
+    const uint32_t before2 = (uint32_t)__shfl((int)(inc2 - s2), (int)l2, 64);
+    c.region = l1 * 64u + l2;
+    c.offset = a2 - before2;
+    c.count = (uint32_t)__shfl((int)s2, (int)l2, 64);
+    return c;
+}
+// Hands the next n records of the slice (n <= 64, n <= c.left) to the lanes with rank 0 .. n-1; `got` tells a lane whether
+// it received one, the value returned is the record's position: region and offset inside it.
+struct SlicePos { uint32_t region, offset; };
+RT_DEV SlicePos slice_take(SliceCursor &c, const uint32_t *__restrict__ counts, uint32_t n, uint32_t rank, bool &got) {
+    SlicePos pos;
+    pos.region = 0; pos.offset = 0;
+    got = false;
+    uint32_t acc = 0;
+    while (acc < n) {
+        if (c.offset >= c.count) {          // on to the next region (its fill is read once, not at every call)
+            c.region++;
+            c.offset = 0;
+            c.count = (uint32_t)__builtin_amdgcn_readfirstlane((int)counts[c.region]);
+            continue;
+        }
+        const uint32_t avail = c.count - c.offset, want = n - acc;
+        const uint32_t use = avail < want ? avail : want;
+        if (rank >= acc && rank < acc + use) { pos.region = c.region; pos.offset = c.offset + (rank - acc); got = true; }
+        acc += use;
+        c.offset += use;
+    }
+    c.left -= n;
+    return pos;
+}
+
 // Position in this wave's queue region for every lane with `pred`; `fill` is wave-uniform.
 RT_DEV uint32_t region_slot(uint32_t &fill, bool pred) {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(pred);
@@ -625,16 +700,16 @@ __global__ __launch_bounds__(64 * WG_WAVES, RT_MIN_WAVES) void k_tail(DScene sc,
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
     uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0;
-    const uint32_t total = b.n_ext[q_in][wave];
-    const size_t region = (size_t)wave * b.region_cap;
+    const uint32_t *counts = b.n_ext[q_in];
+    SliceCursor cur = slice_begin(counts);
     // per-lane state of the path a lane is walking
     PathState ps;
     uint32_t id = 0, kept_flags = 0, light_seed = 0;
     bool alive = false;
     ps.o = ps.d = ps.path = ps.energy = ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
     ps.seed = 0;
-    auto take_record = [&](uint32_t pos) {
-        load_path_rec(b, q_in, region + pos, ps, id, kept_flags);
+    auto take_record = [&](SlicePos at) {
+        load_path_rec(b, q_in, (size_t)at.region * b.region_cap + at.offset, ps, id, kept_flags);
         ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
         if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
         if (kept_flags & KEPT_SPEC) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
@@ -686,16 +761,16 @@ __global__ __launch_bounds__(64 * WG_WAVES, RT_MIN_WAVES) void k_tail(DScene sc,
     };
     // Lanes whose path has ended take the next record of the region, so the wave stays full while lanes are at
     // different depths of different paths.
-    uint32_t next = 0;
     int depth = depth0;
     for (;;) {
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
-        if (next < total && idle != 0ull) {
+        if (cur.left > 0 && idle != 0ull) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const uint32_t avail = total - next, n_idle = (uint32_t)__popcll(idle);
-            const uint32_t take = n_idle < avail ? n_idle : avail;
-            if (!alive && rank < take) { take_record(next + rank); depth = depth0; alive = depth0 < max_depth; }
-            next += take;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t take = n_idle < cur.left ? n_idle : cur.left;
+            bool got;
+            const SlicePos at = slice_take(cur, counts, take, alive ? 64u : rank, got);
+            if (got) { take_record(at); depth = depth0; alive = depth0 < max_depth; }
         }
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         bounce(depth);
