@@ -150,7 +150,7 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
         r.p += size;
     }
     if (!r.ok || chans.empty() || xmax < xmin || ymax < ymin) return fail("bad header");
-    if (compression != 0 && compression != 2 && compression != 3) return fail("compression must be NONE, ZIPS or ZIP");
+    if (compression < 0 || compression > 3) return fail("compression must be NONE, RLE, ZIPS or ZIP");
     width = xmax - xmin + 1;
     height = ymax - ymin + 1;
     const int lines_per_block = compression == 3 ? 16 : 1;
@@ -180,8 +180,28 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
             memcpy(raw.data(), br.p, want);
         } else {
             tmp.resize(want);
-            uLongf got = (uLongf)want;
-            if (uncompress(tmp.data(), &got, br.p, size) != Z_OK || got != want) return fail("zlib error");
+            if (compression == 1) {
+                // run-length code: a count byte n, then n < 0: -n bytes follow as they are, n >= 0: the next byte n + 1 times
+                size_t in = 0, out = 0;
+                while (in < size) {
+                    const int n = (int8_t)br.p[in++];
+                    if (n < 0) {
+                        const size_t len = (size_t)-n;
+                        if (in + len > size || out + len > want) return fail("run-length error");
+                        memcpy(tmp.data() + out, br.p + in, len);
+                        in += len; out += len;
+                    } else {
+                        const size_t len = (size_t)n + 1;
+                        if (in >= size || out + len > want) return fail("run-length error");
+                        memset(tmp.data() + out, br.p[in++], len);
+                        out += len;
+                    }
+                }
+                if (out != want) return fail("run-length error");
+            } else {
+                uLongf got = (uLongf)want;
+                if (uncompress(tmp.data(), &got, br.p, size) != Z_OK || got != want) return fail("zlib error");
+            }
             for (size_t i = 1; i < want; i++) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);     // undo the predictor
             const size_t half = (want + 1) / 2;
             for (size_t i = 0; i < want; i++) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];  // undo the interleave

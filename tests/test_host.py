@@ -132,9 +132,30 @@ def test_exr_roundtrip(tmp_path):
     assert np.array_equal(host.read_exr(p), rgba)
 
 
-def _zip_exr(path, img_half_rgb):
-    """Writes a ZIP-compressed (16-line blocks) HALF RGB scanline EXR with Python, to test the reader."""
+def _rle(data):
+    """OpenEXR's run-length code: count byte n, n < 0: -n literal bytes follow, n >= 0: the next byte n + 1 times."""
+    out, i, n = bytearray(), 0, len(data)
+    while i < n:
+        run = 1
+        while i + run < n and data[i + run] == data[i] and run < 128:
+            run += 1
+        if run >= 3:
+            out += struct.pack("b", run - 1) + bytes([data[i]])
+            i += run
+        else:
+            j = i
+            while j < n and j - i < 127 and not (j + 2 < n and data[j] == data[j + 1] == data[j + 2]):
+                j += 1
+            out += struct.pack("b", -(j - i)) + bytes(data[i:j])
+            i = j
+    return bytes(out)
+
+
+def _zip_exr(path, img_half_rgb, compression=3):
+    """Writes a compressed HALF RGB scanline EXR with Python, to test the reader: 3 = ZIP (16-line blocks),
+    2 = ZIPS (one line per block), 1 = RLE (one line per block)."""
     h, w, _ = img_half_rgb.shape
+    lines = 16 if compression == 3 else 1
 
     def attr(name, typ, val):
         return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
@@ -143,22 +164,22 @@ def _zip_exr(path, img_half_rgb):
         ch += n.encode() + b"\0" + struct.pack("<IBBBBII", 1, 0, 0, 0, 0, 1, 1)
     ch += b"\0"
     box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
-    hdr = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", ch) + attr("compression", "compression", b"\x03")
+    hdr = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", ch) + attr("compression", "compression", bytes([compression]))
     hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
     hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
     hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
     hdr += b"\0"
     blocks = []
-    for y0 in range(0, h, 16):
+    for y0 in range(0, h, lines):
         raw = b""
-        for y in range(y0, min(h, y0 + 16)):
+        for y in range(y0, min(h, y0 + lines)):
             for c in (2, 1, 0):
                 raw += img_half_rgb[y, :, c].astype("<f2").tobytes()
         a = np.frombuffer(raw, np.uint8)
         inter = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
         pred = inter.copy()
         pred[1:] = (inter[1:] - inter[:-1] + 128 + 256) % 256
-        z = zlib.compress(pred.astype(np.uint8).tobytes())
+        z = _rle(pred.astype(np.uint8).tobytes()) if compression == 1 else zlib.compress(pred.astype(np.uint8).tobytes())
         blocks.append((y0, z if len(z) < len(raw) else raw))      # EXR stores a block raw when zlib does not shrink it
     off = len(hdr) + 8 * len(blocks)
     table = b""
@@ -171,11 +192,14 @@ def _zip_exr(path, img_half_rgb):
             fh.write(struct.pack("<ii", y0, len(z)) + z)
 
 
-def test_exr_reader_zip_half(tmp_path):
+@pytest.mark.parametrize("compression", [1, 2, 3])
+def test_exr_reader_compressed_half(tmp_path, compression):
     rng = np.random.default_rng(2)
     img = rng.uniform(0, 2, size=(37, 21, 3)).astype(np.float16)
+    img[5:9, 3:15] = np.float16(0.75)                              # flat areas: runs for the run-length code
+    img[20:, :4] = np.float16(0.0)
     p = str(tmp_path / "z.exr")
-    _zip_exr(p, img)
+    _zip_exr(p, img, compression)
     back = host.read_exr(p)
     assert np.array_equal(back[..., :3], img.astype(np.float32))
 
