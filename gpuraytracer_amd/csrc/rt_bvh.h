@@ -364,6 +364,7 @@ RT_DEV void closest_fold_leaf(const DBvh &bv, const WS &ws, const Ray &ray, int 
     cf.t_min = __builtin_fminf(cf.t_min, tc);
     if (take) { cf.best = id; cf.st.x = rx; cf.st.y = ry; cf.st.z = rd; cf.st.w = det; }
 }
+constexpr int REDO_BY_WAVE_MIN = 1024;
 // Rare cases, redone by the index-order loop: three or more candidates within the margin of the closest
 // depth, or a non-finite ray.  Wave-collective; `redo` selects the lanes.
 RT_DEV void closest_fold_redo(const DScene &sc, const Ray &ray, bool redo, int begin_id, int end_id, int current, float w_init,
@@ -371,7 +372,10 @@ RT_DEV void closest_fold_redo(const DScene &sc, const Ray &ray, bool redo, int b
     if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
         f4 s2;
         s2.x = 0.0f; s2.y = 0.0f; s2.z = -1.0f; s2.w = w_init;
-        const int b2 = closest_hit_range(sc.geo, begin_id, end_id, ray, redo, current, s2, -1);
+        int b2 = -1;
+        // few triangles: every lane walks them with its own ray; many: ray by ray, the lanes share the triangles
+        if (end_id - begin_id < REDO_BY_WAVE_MIN) b2 = closest_hit_range(sc.geo, begin_id, end_id, ray, redo, current, s2, -1);
+        else closest_hit_range_by_wave(sc.geo, begin_id, end_id, ray, redo, current, s2, b2);
         if (redo) { cf.best = b2; cf.st = s2; }
     }
 }

@@ -20,7 +20,10 @@ struct DStats {
 // staging buffer: SAMPLE of every slot of the batch, and its light_seed = CLOCK hashed SAMPLE times
 // (raytracer.glsl:595-598).  The coin of a bounce (raytracer.glsl:553: unitFloat(light_seed) < 0.5, drawn once per
 // bounce from a stream all pixels of a sample share) is recomputed from light_seed where it is needed.
-constexpr int MAX_BATCH = 128;
+#ifndef RT_MAX_BATCH
+#define RT_MAX_BATCH 128
+#endif
+constexpr int MAX_BATCH = RT_MAX_BATCH;
 struct PassTables {
     uint32_t n;
     uint32_t sample[MAX_BATCH];
@@ -67,6 +70,71 @@ RT_DEV int closest_hit_range(const float4 *geo, int begin, int end, const Ray &r
         }
     }
     return best;
+}
+
+// The same fold for few rays over many triangles: one ray at a time, and the 64 lanes of the wave test 64 consecutive
+// triangles of it each round.  Whether a triangle is a candidate (front-facing, in front of the origin, hit inside,
+// not `current`) does not depend on the running state; the candidates of a round are then folded in ascending index
+// order with the shader's "not farther" comparison, the same expression on the same values as in closest_hit_range,
+// so the result is the same bits.  This is what the hierarchy falls back to for the rare ray it cannot decide (three
+// or more candidates within the depth margin, non-finite rays): with closest_hit_range one such ray kept its wave busy
+// for all COUNT triangles, 50 ms and more on a million of them, as long again as the whole launch it is part of.
+// `todo` selects the lanes whose rays are redone; their isec (initialised by the caller) and best are replaced.
+RT_DEV void closest_hit_range_by_wave(const float4 *geo, int begin, int end, const Ray &ray, bool todo, int current, f4 &isec,
+                                      int &best) {
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long left = __builtin_amdgcn_ballot_w64(todo);
+    while (left != 0ull) {
+        const int src = (int)__builtin_ctzll(left);
+        left &= left - 1ull;
+        Ray r;
+        r.o = mk3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ray.o.x), src)),
+                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ray.o.y), src)),
+                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ray.o.z), src)));
+        r.d = mk3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ray.d.x), src)),
+                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ray.d.y), src)),
+                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ray.d.z), src)));
+        const int cur = __builtin_amdgcn_readlane(current, src);
+        f4 st;
+        st.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(isec.x), src));
+        st.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(isec.y), src));
+        st.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(isec.z), src));
+        st.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(isec.w), src));
+        int b = __builtin_amdgcn_readlane(best, src);
+        for (int i0 = begin; i0 < end; i0 += 64) {
+            const int i = i0 + lane;
+            const bool in_range = i < end;
+            const float4 *g = geo + 3 * (size_t)(in_range ? i : begin);
+            const float4 qa = g[0], qb = g[1], qc = g[2];
+            Tri t;
+            t.n = mk3(qa.x, qa.y, qa.z);
+            t.p = mk3(qa.w, qb.x, qb.y);
+            t.u = mk3(qb.z, qb.w, qc.x);
+            t.v = mk3(qc.y, qc.z, qc.w);
+            PlaneTest pt;
+            pt.det = -dot(r.d, t.n);
+            pt.delta = r.o - t.p;
+            pt.rd = dot(t.n, pt.delta);
+            float rx, ry;
+            const bool inside = inside_test(r, t, pt, rx, ry);
+            const bool candidate = in_range & (i != cur) & !((pt.det <= 0.0f) | (pt.rd <= 0.0f)) & inside;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(candidate);
+            while (m != 0ull) {
+                const int l = (int)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const float rd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.rd), l));
+                const float det = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pt.det), l));
+                if (!((st.z >= 0.0f) & (rd * st.w > st.z * det))) {
+                    st.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx), l));
+                    st.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry), l));
+                    st.z = rd;
+                    st.w = det;
+                    b = i0 + l;
+                }
+            }
+        }
+        if (lane == src) { isec = st; best = b; }
+    }
 }
 
 RT_DEV int closest_hit_bf(const DScene &sc, const Ray &ray, f4 &isec) {
