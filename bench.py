@@ -185,7 +185,7 @@ def main():
 
     import torch
     import gpuraytracer_amd as g
-    from gpuraytracer_amd.distributed import reduce_sums, shard_samples
+    from gpuraytracer_amd.distributed import reduce_sums, step_plan
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -206,12 +206,12 @@ def main():
     spp = args.spp_per_step
     strong = args.total_spp > 0
     if strong:
-        # this rank's share of the image's samples, rendered in steps of `spp`; every rank times the same step count
-        _, my_count, _ = shard_samples(args.total_spp, rank, world)
-        steps = (shard_samples(args.total_spp, 0, world)[1] + spp - 1) // spp
+        # this rank's share of the image's samples, rendered in steps of `spp`; every rank takes the same number of steps
+        plan = step_plan(args.total_spp, rank, world, spp)
     else:
-        my_count = args.steps * spp
-        steps = args.steps
+        plan = [(rank + world * (i * spp), spp, world) for i in range(args.steps)]
+    steps = len(plan)
+    my_count = sum(n for _, n, _ in plan)
 
     ctx = g.Context(local_rank)
     ctx.set_option("pipeline", args.pipeline)
@@ -247,11 +247,10 @@ def main():
     ctx.set_frame(cam, clock, RECURSION, 1.0)
 
     def step(i):
-        # SAMPLE indices of this rank: rank + world * k for k in [i * spp, (i + 1) * spp), cut at this rank's share
-        first = i * spp
-        n = min(spp, my_count - first) if i < steps else spp
+        # SAMPLE indices of this rank: rank + world * k; warm-up steps (i >= steps) render samples beyond the timed ones
+        begin, n, stride = plan[i] if i < steps else (rank + world * (i * spp), spp, world)
         if n > 0:
-            ctx.trace(rank + world * first, n, world)
+            ctx.trace(begin, n, stride)
 
     def barrier():
         torch.cuda.synchronize()

@@ -15,6 +15,24 @@ def shard_samples(total_samples, rank, world_size):
     return rank, count, world_size
 
 
+def step_plan(total_samples, rank, world_size, samples_per_step):
+    """A fixed image of `total_samples` samples rendered in steps of `samples_per_step` per rank (strong scaling): every
+    rank takes the same number of steps, ceil(share of rank 0 / samples_per_step), so that barriers and timing line up;
+    a rank whose share is used up renders nothing in the remaining steps.  Returns a list with one
+    (sample_begin, sample_count, sample_stride) per step for rt_trace (sample_count may be 0)."""
+    if samples_per_step < 1:
+        raise ValueError("samples_per_step must be positive")
+    _, largest, _ = shard_samples(total_samples, 0, world_size)
+    _, mine, _ = shard_samples(total_samples, rank, world_size)
+    steps = (largest + samples_per_step - 1) // samples_per_step
+    plan = []
+    for i in range(steps):
+        first = i * samples_per_step
+        n = max(0, min(samples_per_step, mine - first))
+        plan.append((rank + world_size * first, n, world_size))
+    return plan
+
+
 def reduce_sums(tensor, dst=0, group=None, ordered=True):
     """Adds the per-rank sum buffers onto rank `dst` (in place).  Call on every rank.
 

@@ -9,7 +9,7 @@ import pytest
 
 from conftest import constant_env, load_scene
 from gpuraytracer_amd.camera import camera_matrix, DEFAULT_CLOCK
-from gpuraytracer_amd.distributed import mean_image, reduce_sums, shard_samples
+from gpuraytracer_amd.distributed import mean_image, reduce_sums, shard_samples, step_plan
 
 W, H, SPP = 24, 16, 7          # 7 samples: 4 + 3 on two ranks, 3 + 2 + 2 on three
 
@@ -24,6 +24,20 @@ def test_shard_samples_partition():
             assert sorted(seen) == list(range(total))
     with pytest.raises(ValueError):
         shard_samples(4, 2, 2)
+
+
+@pytest.mark.parametrize("total,world,per_step", [(4096, 8, 128), (7, 3, 2), (5, 8, 64), (1000, 3, 128), (1, 1, 1)])
+def test_step_plan_covers_every_sample_once(total, world, per_step):
+    plans = [step_plan(total, r, world, per_step) for r in range(world)]
+    assert len({len(p) for p in plans}) == 1                      # every rank takes the same number of steps
+    seen = []
+    for p in plans:
+        for begin, n, stride in p:
+            assert 0 <= n <= per_step and stride == world
+            seen += [begin + k * stride for k in range(n)]
+    assert sorted(seen) == list(range(total))
+    # rank 0 is never idle in a step but possibly the last one
+    assert all(n == per_step for _, n, _ in plans[0][:-1])
 
 
 def _worker(rank, world, port, out_path):
