@@ -136,7 +136,9 @@ DBvh device_bvh(const rt_context *ctx, const rt_context::DevBvh &b, bool want) {
     d.enabled = (want && b.ok) ? 1 : 0;
     d.n_nodes = b.n_nodes;
     d.n_slots = b.n_slots;
-    (void)ctx;
+    // a traversal pushes at most one child per level
+    const int deepest = std::max(ctx->bvh.depth, ctx->light_bvh.ok ? ctx->light_bvh.depth : 0);
+    d.stack_entries = std::min(BVH_STACK, std::max(8, deepest + 2));
     return d;
 }
 

@@ -43,6 +43,7 @@ struct DBvh {
     int enabled;
     int n_nodes;
     int n_slots;             // leaf slots (= triangles)
+    int stack_entries;       // traversal stack entries per lane that this hierarchy and the one searched beside it need
 };
 
 #ifndef RT_BVH_STACK

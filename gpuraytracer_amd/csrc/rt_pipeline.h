@@ -159,8 +159,9 @@ struct KernelCfg {
     // LDS of a workgroup: the stacks; then either the cached tops of the two hierarchies (192 + 64 nodes; with SHARE the
     // last 16 node slots of the second are the waves' 128-byte exchange areas) or the resident scene and 1 KB of
     // exchange areas.  80 KB at most: two workgroups per CU.
-    static constexpr int STACK_INTS = BVH_ ? STACK * 64 * WG_WAVES : 64;
-    static constexpr int SCENE_V4F = !BVH_ ? 1 : (RES_ ? RES_BYTES / 16 : (BVH_TOP_NODES + BVH_LIGHT_TOP_NODES) * 4);
+    // (the non-resident form carves stacks, cached nodes and exchange areas out of one array at run time, see stage_hierarchies)
+    static constexpr int STACK_INTS = !BVH_ ? 64 : (RES_ ? STACK * 64 * WG_WAVES : BVH_STACK * 64 * WG_WAVES + (BVH_TOP_NODES + BVH_LIGHT_TOP_NODES) * 16);
+    static constexpr int SCENE_V4F = (BVH_ && RES_) ? RES_BYTES / 16 : 1;
     static constexpr int SHARE_BYTES = (BVH_ && RES_) ? 128 * WG_WAVES : 1;
 };
 
@@ -194,11 +195,28 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
         }
         share = (lds_u8_ptr)share_mem + 128 * wv;
     } else {
-        v4f *light_top = scene_mem + BVH_TOP_NODES * 4;
-        ws.n_top = bvh_stage_top(bv, scene_mem);
+        // The stacks take what the depth of the hierarchies asks for (bv.stack_entries per lane) and the rest of the
+        // array caches nodes: the first ones of the light hierarchy (all of it if it has up to 128 nodes and a third
+        // of the room suffices) and, in what is left, the first ones of the scene's.  The waves' exchange areas are
+        // the last 16 node slots.
+        const int entries = bv.stack_entries;
+        ws.stack = stack_mem + wv * (entries * 64) + lane;
+        v4f *free_mem = (v4f *)(stack_mem + WG_WAVES * entries * 64);
+        const int room = (CFG::STACK_INTS - WG_WAVES * entries * 64) / 16 - 16;        // 64-byte node slots
+        int light_slots = 0;
+        if (with_light && lbv.enabled) {
+            light_slots = lbv.n_nodes < 128 ? lbv.n_nodes : 128;
+            if (light_slots > room / 3) light_slots = room / 3;
+        }
+        const int scene_slots = room - light_slots;
+        v4f *light_top = free_mem + scene_slots * 4;
+        ws.top = (lds_v4f_ptr)free_mem;
+        ws.n_top = bvh_stage_top(bv, free_mem, scene_slots);
+        lws = ws;
         lws.top = (lds_v4f_ptr)light_top;
-        if (with_light) lws.n_top = bvh_stage_top(lbv, light_top, CFG::SHARE ? BVH_LIGHT_TOP_NODES - 16 : BVH_LIGHT_TOP_NODES);
-        share = (lds_u8_ptr)&light_top[(BVH_LIGHT_TOP_NODES - 16) * 4] + 128 * wv;
+        lws.n_top = 0;
+        if (with_light) lws.n_top = bvh_stage_top(lbv, light_top, light_slots);
+        share = (lds_u8_ptr)(free_mem + room * 4) + 128 * wv;
     }
 }
 #define RT_TRAVERSAL_LDS(CFG)                                              \
