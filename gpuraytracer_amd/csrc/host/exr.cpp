@@ -122,9 +122,11 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
     Reader r{data.data(), data.data() + data.size()};
     if (r.u32() != 20000630u) return fail("not an OpenEXR file");
     const uint32_t version = r.u32();
-    if ((version & 0xFFu) != 2 || (version & 0x1E00u)) return fail("only single-part scanline files are supported");
+    if ((version & 0xFFu) != 2 || (version & 0x1C00u)) return fail("only single-part files without deep data are supported");
+    const bool tiled = (version & 0x200u) != 0;
     std::vector<Channel> chans;
     int compression = -1, xmin = 0, ymin = 0, xmax = -1, ymax = -1;
+    uint32_t tile_w = 0, tile_h = 0, tile_mode = 0;
     while (r.ok) {
         const std::string name = r.str();
         if (name.empty()) break;
@@ -146,15 +148,18 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
             compression = size ? (int)*a.p : -1;
         } else if (name == "dataWindow") {
             xmin = (int)a.u32(); ymin = (int)a.u32(); xmax = (int)a.u32(); ymax = (int)a.u32();
+        } else if (name == "tiles") {
+            tile_w = a.u32(); tile_h = a.u32();
+            tile_mode = size > 8 ? (uint32_t)a.p[0] : 0u;
         }
         r.p += size;
     }
     if (!r.ok || chans.empty() || xmax < xmin || ymax < ymin) return fail("bad header");
     if (compression < 0 || compression > 3) return fail("compression must be NONE, RLE, ZIPS or ZIP");
+    if (tiled && (tile_w == 0 || tile_h == 0)) return fail("tiled file without a tile description");
+    if (tiled && (tile_mode & 0xFu) != 0) return fail("only tiled files with one level are supported");
     width = xmax - xmin + 1;
     height = ymax - ymin + 1;
-    const int lines_per_block = compression == 3 ? 16 : 1;
-    const int blocks = (height + lines_per_block - 1) / lines_per_block;
     size_t pixel_bytes = 0;
     for (const Channel &c : chans) {
         if (c.type != 1 && c.type != 2) return fail("channel type must be HALF or FLOAT");
@@ -162,67 +167,95 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
     }
     rgba.assign((size_t)width * height * 4, 0.0f);
     for (size_t i = 0; i < (size_t)width * height; i++) rgba[i * 4 + 3] = 1.0f;
-    std::vector<uint64_t> offsets(blocks);
-    for (int i = 0; i < blocks; i++) offsets[i] = r.u64();
-    if (!r.ok) return fail("truncated offset table");
+
+    // A block is a run of scanlines over the full width, or one tile: rows [y0, y0 + rows) x columns [x0, x0 + cols),
+    // stored row by row, channel by channel within a row.
     std::vector<uint8_t> raw, tmp;
-    for (int bidx = 0; bidx < blocks; bidx++) {
-        if (offsets[bidx] + 8 > data.size()) return fail("bad block offset");
-        Reader br{data.data() + offsets[bidx], data.data() + data.size()};
-        const int y0 = (int)br.u32() - ymin;
-        const uint32_t size = br.u32();
-        if (!br.ok || (size_t)(br.end - br.p) < size || y0 < 0 || y0 >= height) return fail("bad block");
-        const int nlines = std::min(lines_per_block, height - y0);
-        const size_t want = pixel_bytes * (size_t)width * nlines;
+    auto decode_block = [&](const uint8_t *src, uint32_t size, int x0, int y0, int cols, int rows) -> const char * {
+        const size_t want = pixel_bytes * (size_t)cols * rows;
         raw.resize(want);
         if (compression == 0 || size == want) {
-            if (size != want) return fail("bad block size");
-            memcpy(raw.data(), br.p, want);
+            if (size != want) return "bad block size";
+            memcpy(raw.data(), src, want);
         } else {
             tmp.resize(want);
             if (compression == 1) {
                 // run-length code: a count byte n, then n < 0: -n bytes follow as they are, n >= 0: the next byte n + 1 times
                 size_t in = 0, out = 0;
                 while (in < size) {
-                    const int n = (int8_t)br.p[in++];
+                    const int n = (int8_t)src[in++];
                     if (n < 0) {
                         const size_t len = (size_t)-n;
-                        if (in + len > size || out + len > want) return fail("run-length error");
-                        memcpy(tmp.data() + out, br.p + in, len);
+                        if (in + len > size || out + len > want) return "run-length error";
+                        memcpy(tmp.data() + out, src + in, len);
                         in += len; out += len;
                     } else {
                         const size_t len = (size_t)n + 1;
-                        if (in >= size || out + len > want) return fail("run-length error");
-                        memset(tmp.data() + out, br.p[in++], len);
+                        if (in >= size || out + len > want) return "run-length error";
+                        memset(tmp.data() + out, src[in++], len);
                         out += len;
                     }
                 }
-                if (out != want) return fail("run-length error");
+                if (out != want) return "run-length error";
             } else {
                 uLongf got = (uLongf)want;
-                if (uncompress(tmp.data(), &got, br.p, size) != Z_OK || got != want) return fail("zlib error");
+                if (uncompress(tmp.data(), &got, src, size) != Z_OK || got != want) return "zlib error";
             }
             for (size_t i = 1; i < want; i++) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);     // undo the predictor
             const size_t half = (want + 1) / 2;
             for (size_t i = 0; i < want; i++) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];  // undo the interleave
         }
         const uint8_t *p = raw.data();
-        for (int l = 0; l < nlines; l++) {
+        for (int l = 0; l < rows; l++) {
             for (const Channel &c : chans) {
                 int dst = -1;
                 if (c.name == "R") dst = 0; else if (c.name == "G") dst = 1; else if (c.name == "B") dst = 2;
                 else if (c.name == "A") dst = 3;
                 const size_t esz = c.type == 1 ? 2 : 4;
                 if (dst >= 0)
-                    for (int x = 0; x < width; x++) {
+                    for (int x = 0; x < cols; x++) {
                         float v;
                         if (c.type == 1) { uint16_t h; memcpy(&h, p + x * 2, 2); v = half_to_float(h); }
                         else memcpy(&v, p + (size_t)x * 4, 4);
-                        rgba[((size_t)(y0 + l) * width + x) * 4 + dst] = v;
+                        rgba[((size_t)(y0 + l) * width + (x0 + x)) * 4 + dst] = v;
                     }
-                p += esz * width;
+                p += esz * cols;
             }
         }
+        return nullptr;
+    };
+
+    if (tiled) {
+        const int nx = (width + (int)tile_w - 1) / (int)tile_w, ny = (height + (int)tile_h - 1) / (int)tile_h;
+        std::vector<uint64_t> offsets((size_t)nx * ny);
+        for (uint64_t &o : offsets) o = r.u64();
+        if (!r.ok) return fail("truncated offset table");
+        for (uint64_t off : offsets) {
+            if (off + 20 > data.size()) return fail("bad tile offset");
+            Reader br{data.data() + off, data.data() + data.size()};
+            const int tx = (int)br.u32(), ty = (int)br.u32();
+            const uint32_t lx = br.u32(), ly = br.u32(), size = br.u32();
+            if (!br.ok || (size_t)(br.end - br.p) < size || tx < 0 || ty < 0 || tx >= nx || ty >= ny || lx != 0 || ly != 0)
+                return fail("bad tile");
+            const int x0 = tx * (int)tile_w, y0 = ty * (int)tile_h;
+            const char *what = decode_block(br.p, size, x0, y0, std::min((int)tile_w, width - x0), std::min((int)tile_h, height - y0));
+            if (what) return fail(what);
+        }
+        return true;
+    }
+    const int lines_per_block = compression == 3 ? 16 : 1;
+    const int blocks = (height + lines_per_block - 1) / lines_per_block;
+    std::vector<uint64_t> offsets(blocks);
+    for (int i = 0; i < blocks; i++) offsets[i] = r.u64();
+    if (!r.ok) return fail("truncated offset table");
+    for (int bidx = 0; bidx < blocks; bidx++) {
+        if (offsets[bidx] + 8 > data.size()) return fail("bad block offset");
+        Reader br{data.data() + offsets[bidx], data.data() + data.size()};
+        const int y0 = (int)br.u32() - ymin;
+        const uint32_t size = br.u32();
+        if (!br.ok || (size_t)(br.end - br.p) < size || y0 < 0 || y0 >= height) return fail("bad block");
+        const char *what = decode_block(br.p, size, 0, y0, width, std::min(lines_per_block, height - y0));
+        if (what) return fail(what);
     }
     return true;
 }

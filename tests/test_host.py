@@ -204,6 +204,60 @@ def test_exr_reader_compressed_half(tmp_path, compression):
     assert np.array_equal(back[..., :3], img.astype(np.float32))
 
 
+def _tiled_exr(path, img_rgb, tile_w, tile_h, compression):
+    """Writes a tiled (one level) FLOAT RGB EXR with Python: version flag 0x200, a `tiles` attribute, one offset per
+    tile in row-major tile order, each tile with its coordinates, level (0, 0), size and data (rows of the tile,
+    channels B, G, R within a row), compressed like a scanline block."""
+    h, w, _ = img_rgb.shape
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
+    ch = b""
+    for n in ("B", "G", "R"):
+        ch += n.encode() + b"\0" + struct.pack("<IBBBBII", 2, 0, 0, 0, 0, 1, 1)
+    ch += b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr = struct.pack("<II", 20000630, 2 | 0x200) + attr("channels", "chlist", ch)
+    hdr += attr("compression", "compression", bytes([compression]))
+    hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
+    hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tile_w, tile_h, 0)) + b"\0"
+    tiles = []
+    for ty in range((h + tile_h - 1) // tile_h):
+        for tx in range((w + tile_w - 1) // tile_w):
+            part = img_rgb[ty * tile_h:(ty + 1) * tile_h, tx * tile_w:(tx + 1) * tile_w]
+            raw = b"".join(part[y, :, c].astype("<f4").tobytes() for y in range(part.shape[0]) for c in (2, 1, 0))
+            data = raw
+            if compression:
+                a = np.frombuffer(raw, np.uint8)
+                inter = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+                pred = inter.copy()
+                pred[1:] = (inter[1:] - inter[:-1] + 128 + 256) % 256
+                z = _rle(pred.astype(np.uint8).tobytes()) if compression == 1 else zlib.compress(pred.astype(np.uint8).tobytes())
+                data = z if len(z) < len(raw) else raw
+            tiles.append(struct.pack("<iiiii", tx, ty, 0, 0, len(data)) + data)
+    off = len(hdr) + 8 * len(tiles)
+    table = b""
+    for t in tiles:
+        table += struct.pack("<Q", off)
+        off += len(t)
+    with open(path, "wb") as fh:
+        fh.write(hdr + table + b"".join(tiles))
+
+
+@pytest.mark.parametrize("compression", [0, 1, 3])
+def test_exr_reader_tiled(tmp_path, compression):
+    rng = np.random.default_rng(4)
+    img = rng.uniform(0, 3, size=(45, 70, 3)).astype(np.float32)     # 32 x 16 tiles: ragged on both edges
+    img[10:20, 5:60] = np.float32(1.5)
+    p = str(tmp_path / "t.exr")
+    _tiled_exr(p, img, 32, 16, compression)
+    back = host.read_exr(p)
+    assert back.shape == (45, 70, 4)
+    assert np.array_equal(back[..., :3], img) and (back[..., 3] == 1).all()
+
+
 def test_camera_matrix_matches_python_recipe():
     for t, r in (((0.0, 1.5, -3.0), (-np.pi / 4, 0.0)), ((0.3, 1.2, -2.5), (-0.5, 0.4))):
         assert np.allclose(host.camera_matrix(t, r), camera_matrix(t, r), atol=1e-7)
