@@ -357,6 +357,7 @@ RT_DEV SlicePos slice_take(SliceCursor &c, const uint32_t *__restrict__ counts, 
     uint32_t acc = 0;
     while (acc < n) {
         if (c.offset >= c.count) {          // on to the next region (its fill is read once, not at every call)
+            if (c.region + 1u >= (uint32_t)PIPE_WAVES) { c.left = n; break; }    // cannot happen while the counts hold still
             c.region++;
             c.offset = 0;
             c.count = (uint32_t)__builtin_amdgcn_readfirstlane((int)counts[c.region]);

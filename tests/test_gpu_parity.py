@@ -677,6 +677,21 @@ def test_million_triangles_hierarchy_equals_loop(gpu_ctx, million_triangles):
             assert st[key] == wst[key], (pipeline, key)
 
 
+def test_million_triangles_full_size_forms_agree(gpu_ctx, million_triangles):
+    # 1920 x 1080 on the 1 M-triangle scene, 3 samples in one pass and in passes of 2 + 1: the library's own choice of
+    # forms (lane refill, budgeted shared searches, chunks handed out as waves become free, tail kernel on even slices)
+    # against every lane searching alone with every bounce staged, bit for bit, with equal counters
+    _upload(gpu_ctx, million_triangles, gradient_env())
+    cam = camera_matrix((0.0, 2.2, -5.5), (-0.45, 0.0))
+    a, sa = _render(gpu_ctx, 1920, 1080, 0, 3, clock=99, pipeline=1, batch=3, cam=cam)
+    b, sb = _render(gpu_ctx, 1920, 1080, 0, 3, clock=99, pipeline=7, batch=2, cam=cam)
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), int((~same).sum())
+    for key in ("rays", "shadow_probes", "glossy_probes", "pixel_samples"):
+        assert sa[key] == sb[key], key
+    assert sa["rays"] > 1.15 * sa["pixel_samples"] and np.isfinite(a).mean() > 0.999
+
+
 def _read_exr_uncompressed(path):
     """OpenEXR scanline file without compression, FLOAT channels, read with nothing but struct: returns
     ({channel name: [h, w] float32}, channel names in file order, header attributes)."""
