@@ -16,9 +16,11 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/gpurt.h"
@@ -65,12 +67,13 @@ inline int max_leaf_for(uint32_t count) { return count >= 65536u ? 2 : (count < 
 #define RT_BVH_BINS 32
 #endif
 constexpr int BINS = RT_BVH_BINS;
+constexpr uint32_t PARALLEL_BUILD_MIN = 32768;     // triangles from which on subtrees are built by several threads
 
 }  // namespace bvh_detail
 
 // Builds the hierarchy over `count` triangles.  `force_median`: split by object median only (bounded
 // depth); used when the SAH tree would come out deeper than the traversal stack.
-inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool force_median, HostBvh &out) {
+inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool force_median, HostBvh &result) {
     using namespace bvh_detail;
     const int MAX_LEAF = max_leaf_for(count);
     std::vector<Item> items(count);
@@ -96,14 +99,19 @@ inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool f
         it.id = (int32_t)i;
         const double n2 = (double)t.true_normal[0] * t.true_normal[0] + (double)t.true_normal[1] * t.true_normal[1] +
                           (double)t.true_normal[2] * t.true_normal[2];
-        if (n2 > 0.0 && n2 < out.min_normal_len2) out.min_normal_len2 = n2;
+        if (n2 > 0.0 && n2 < result.min_normal_len2) result.min_normal_len2 = n2;
     }
-    out.nodes.clear();
-    out.leaf_geo.clear();
-    out.leaf_ids.clear();
-    out.depth = 0;
-    out.max_abs_coord = max_abs;
+    result.nodes.clear();
+    result.leaf_geo.clear();
+    result.leaf_ids.clear();
+    result.depth = 0;
+    result.max_abs_coord = max_abs;
 
+    struct Task { uint32_t begin, end; int32_t parent; int slot; int depth; };
+    // Builds the subtree of `first` into `out` (a HostBvh or a Fragment: node and leaf-slot numbers count from the start
+    // of `out`).  With `deferred`, ranges of `defer_n` items or fewer are not built but listed, their box written to the
+    // parent and their link left open: they are built by other threads and appended afterwards.
+    auto build_tasks = [&](auto &out, const Task &first, uint32_t defer_n, std::vector<Task> *deferred) {
     auto pad_box = [](Box b) {
         for (int a = 0; a < 3; a++) {
             const float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
@@ -128,15 +136,25 @@ inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool f
         return ~(int32_t)((first << 3) | (end - begin));
     };
 
-    struct Task { uint32_t begin, end; int32_t parent; int slot; int depth; };
     std::vector<Task> stack;
-    // root: always an inner node (a scene of <= MAX_LEAF triangles gets one leaf child and one empty child)
-    stack.push_back({0, count, -1, 0, 1});
+    // the first task always becomes an inner node (a scene of <= MAX_LEAF triangles gets one leaf child and one empty child)
+    stack.push_back(first);
     while (!stack.empty()) {
         const Task t = stack.back();
         stack.pop_back();
         out.depth = std::max(out.depth, t.depth);
         const uint32_t n = t.end - t.begin;
+        if (deferred && t.parent >= 0 && n > (uint32_t)MAX_LEAF && n <= defer_n) {
+            float *nd = &out.nodes[(size_t)t.parent * 16];
+            Box b;
+            b.reset();
+            for (uint32_t i = t.begin; i < t.end; i++) b.grow(items[i].box);
+            b = pad_box(b);
+            float *dst = nd + 6 * t.slot;
+            dst[0] = b.lo[0]; dst[1] = b.lo[1]; dst[2] = b.lo[2]; dst[3] = b.hi[0]; dst[4] = b.hi[1]; dst[5] = b.hi[2];
+            deferred->push_back(t);
+            continue;
+        }
         int32_t self;
         if (n <= (uint32_t)MAX_LEAF && t.parent >= 0) {
             self = make_leaf(t.begin, t.end);
@@ -230,6 +248,55 @@ inline void build_bvh_impl(const rt_triangle_model *tris, uint32_t count, bool f
             dst[0] = b.lo[0]; dst[1] = b.lo[1]; dst[2] = b.lo[2]; dst[3] = b.hi[0]; dst[4] = b.hi[1]; dst[5] = b.hi[2];
             memcpy(&nd[12 + t.slot], &self, 4);
         }
+    }
+    };
+
+    // Large scenes: the top of the tree is built here, subtrees of count / 64 triangles or fewer by a pool of threads
+    // (their item ranges are disjoint), then appended in the order they were met.  The tree does not depend on the
+    // number of threads; only the numbering of the leaf slots differs from a build in one go.
+    struct Fragment { std::vector<float> nodes, leaf_geo; std::vector<int32_t> leaf_ids; int depth = 0; };
+    const uint32_t defer_n = count >= PARALLEL_BUILD_MIN ? count / 64u : 0u;
+    std::vector<Task> deferred;
+    build_tasks(result, Task{0, count, -1, 0, 1}, defer_n, defer_n ? &deferred : nullptr);
+    if (deferred.empty()) return;
+    std::vector<Fragment> parts(deferred.size());
+    std::atomic<size_t> next(0);
+    auto worker = [&]() {
+        for (size_t k = next.fetch_add(1); k < deferred.size(); k = next.fetch_add(1)) {
+            Task root = deferred[k];
+            root.parent = -1;
+            build_tasks(parts[k], root, 0u, nullptr);
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = std::min<size_t>(deferred.size(), std::max(1u, std::min(hw ? hw : 1u, 16u)));
+    std::vector<std::thread> pool;
+    for (size_t k = 1; k < n_threads; k++) pool.emplace_back(worker);
+    worker();
+    for (std::thread &th : pool) th.join();
+    for (size_t k = 0; k < deferred.size(); k++) {
+        const Fragment &f = parts[k];
+        const int32_t node0 = (int32_t)(result.nodes.size() / 16);
+        const uint32_t slot0 = (uint32_t)result.leaf_ids.size();
+        const size_t at = result.nodes.size();
+        result.nodes.insert(result.nodes.end(), f.nodes.begin(), f.nodes.end());
+        for (size_t n = 0; n < f.nodes.size() / 16; n++)
+            for (int c = 0; c < 2; c++) {
+                int32_t link;
+                float *where = &result.nodes[at + n * 16 + 12 + c];
+                memcpy(&link, where, 4);
+                if (link >= 0) {
+                    link += node0;
+                } else {
+                    const uint32_t code = (uint32_t)~link;
+                    link = ~(int32_t)((((code >> 3) + slot0) << 3) | (code & 7u));
+                }
+                memcpy(where, &link, 4);
+            }
+        result.leaf_geo.insert(result.leaf_geo.end(), f.leaf_geo.begin(), f.leaf_geo.end());
+        result.leaf_ids.insert(result.leaf_ids.end(), f.leaf_ids.begin(), f.leaf_ids.end());
+        memcpy(&result.nodes[(size_t)deferred[k].parent * 16 + 12 + deferred[k].slot], &node0, 4);
+        result.depth = std::max(result.depth, f.depth);
     }
 }
 
