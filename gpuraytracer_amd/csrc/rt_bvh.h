@@ -28,7 +28,8 @@
 // r = 2^-16 * (largest |coordinate| of the scene and of its origin), far above the rounding of the
 // triangle test (which works on the unrounded p, u, v), far below any geometric feature.
 // Rays with a non-finite origin or direction take the index-order loop (for them "every comparison
-// is false" makes the last triangle win, which no box test reproduces).
+// is false" makes the last triangle win, which no box test reproduces).  A direction component of zero (or
+// below 2^-64) takes its axis out of the box test, see bvh_ray_setup.
 #pragma once
 
 #include "rt_kernels.h"
@@ -129,6 +130,17 @@ struct BvhRay {
     bool finite;
 };
 
+// Rays the box tests can serve: finite, and with the origin and the scene inside +-2^60, so that with |1/d| capped at
+// 2^64 (below) no product of a slab test overflows.  All others take the index-order loops.
+constexpr float BVH_MAX_COORD = 0x1p60f;
+constexpr float BVH_MAX_INV = 0x1p64f;
+RT_DEV bool bvh_ray_ok(const Ray &ray, float max_abs_coord) {
+    const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y)),
+                                    __builtin_fmaxf(__builtin_fabsf(ray.o.z), max_abs_coord));
+    return ((s - s) == 0.0f) & (m < BVH_MAX_COORD);      // s - s is NaN when any component is NaN or infinite
+}
+
 template <bool RES>
 RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
     BvhRay b;
@@ -137,22 +149,37 @@ RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
     const float r = m * (1.0f / 65536.0f) + 1e-30f;
     // reciprocal to 1 ulp: the slab test is conservative by far more than that
     b.inv = mk3(__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z));
+    // A direction component of (nearly) zero: its reciprocal is infinite or huge, the two terms of a slab test become
+    // infinities, and their difference NaN or an infinity of the wrong sign.  Such an axis is left out of the test
+    // instead (reciprocal 0, constants that put its planes at -max / +max): every box counts as entered along it,
+    // which only costs a ray parallel to an axis some box tests.
+    const bool flat_x = !(__builtin_fabsf(b.inv.x) <= BVH_MAX_INV), flat_y = !(__builtin_fabsf(b.inv.y) <= BVH_MAX_INV),
+               flat_z = !(__builtin_fabsf(b.inv.z) <= BVH_MAX_INV);
+    if (flat_x) b.inv.x = 0.0f;
+    if (flat_y) b.inv.y = 0.0f;
+    if (flat_z) b.inv.z = 0.0f;
+    constexpr float FAR = 3.4028234664e38f;
     if (RES) {
         // r with the sign of the direction: the plane met first is lo for a positive direction (constant origin + r), hi
         // for a negative one (constant origin - r)
         const float rx = __builtin_copysignf(r, b.inv.x), ry = __builtin_copysignf(r, b.inv.y), rz = __builtin_copysignf(r, b.inv.z);
         b.ca = mk3((ray.o.x + rx) * b.inv.x, (ray.o.y + ry) * b.inv.y, (ray.o.z + rz) * b.inv.z);
         b.cb = mk3((ray.o.x - rx) * b.inv.x, (ray.o.y - ry) * b.inv.y, (ray.o.z - rz) * b.inv.z);
+        if (flat_x) { b.ca.x = FAR; b.cb.x = -FAR; }
+        if (flat_y) { b.ca.y = FAR; b.cb.y = -FAR; }
+        if (flat_z) { b.ca.z = FAR; b.cb.z = -FAR; }
         b.off_x = (int)((__float_as_uint(b.inv.x) >> 29) & 4u);
         b.off_y = (int)((__float_as_uint(b.inv.y) >> 29) & 4u) + 24;
         b.off_z = (int)((__float_as_uint(b.inv.z) >> 29) & 4u) + 48;
     } else {
         b.ca = mk3((ray.o.x - r) * b.inv.x, (ray.o.y - r) * b.inv.y, (ray.o.z - r) * b.inv.z);
         b.cb = mk3((ray.o.x + r) * b.inv.x, (ray.o.y + r) * b.inv.y, (ray.o.z + r) * b.inv.z);
+        if (flat_x) { b.ca.x = -FAR; b.cb.x = FAR; }
+        if (flat_y) { b.ca.y = -FAR; b.cb.y = FAR; }
+        if (flat_z) { b.ca.z = -FAR; b.cb.z = FAR; }
         b.off_x = b.off_y = b.off_z = 0;
     }
-    const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
-    b.finite = (s - s) == 0.0f;      // false when any component is NaN or infinite
+    b.finite = bvh_ray_ok(ray, max_abs_coord);
     return b;
 }
 // The address offsets of the resident form again, from the reciprocal direction (cheaper than carrying them to another lane).
@@ -164,8 +191,8 @@ RT_DEV void bvh_ray_offsets(BvhRay &b) {
 
 // Slab test against a box widened by r (one fused multiply-add per plane; this test only has to be
 // conservative, it takes no part in the hit arithmetic).  Gives the entry distance (clamped at 0) and the exit
-// distance (clamped at `t_max`); the box is entered within t_max iff t_in <= t_out.  min/max ignore NaN
-// (inf - inf for a ray parallel to a slab), which errs on the side of visiting.  The rounding of these
+// distance (clamped at `t_max`); the box is entered within t_max iff t_in <= t_out.  bvh_ray_setup keeps
+// infinities and NaN out of the terms.  The rounding of these
 // operations (a few 2^-24 of |origin| * |inv|) is below 1/16 of the widening r * |inv| = 2^-16 * |origin| * |inv|.
 RT_DEV void box_slabs(const BvhRay &br, f3 lo, f3 hi, float t_max, float &t_in, float &t_out) {
     const float ax = __builtin_fmaf(lo.x, br.inv.x, -br.cb.x), bx = __builtin_fmaf(hi.x, br.inv.x, -br.ca.x);
@@ -550,8 +577,7 @@ RT_DEV int glossy_search_bvh(const DScene &sc, const DBvh &bv, const DBvh &lbv, 
 template <int NODE_BUDGET, class WS>
 RT_DEV bool shadow_any_hit_shared(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
                                   const WS &ws, lds_u8_ptr scratch, BvhCounters &cnt) {
-    const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
-    const bool ok = ((s - s) == 0.0f) && ((max_t - max_t) == 0.0f);
+    const bool ok = bvh_ray_ok(ray, bv.max_abs_coord) && ((max_t - max_t) == 0.0f);
     auto test = [&](const Ray &r, const f3 &e, int slot) -> bool {
         const Tri t = load_leaf_tri(bv, ws, slot);
         return intersect_triangle_shadow(r, t, e.x) && leaf_tri_id(bv, ws, slot) != __float_as_int(e.z);
@@ -579,10 +605,9 @@ RT_DEV int glossy_search_shared(const DScene &sc, const DBvh &bv, const DBvh &lb
     }
     bool blocked = false;
     if (lights < count) {
-        const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
         const bool bounded = isec.z >= 0.0f;                 // a light was hit: only triangles not farther than it matter
         const float t_light = isec.z / isec.w;
-        const bool ok = ((s - s) == 0.0f) && (!bounded || (t_light - t_light) == 0.0f);
+        const bool ok = bvh_ray_ok(ray, bv.max_abs_coord) && (!bounded || (t_light - t_light) == 0.0f);
         auto test = [&](const Ray &r, const f3 &e, int slot) -> bool {
             const Tri t = load_leaf_tri(bv, ws, slot);
             f4 st;

@@ -242,6 +242,20 @@ template <class CFG>
 RT_DEV int glossy_search_cfg(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &probe, int current, bool run,
                              int &light_id, f4 &lsec, const typename CFG::WS &ws, const typename CFG::WS &lws, lds_u8_ptr share,
                              BvhCounters &cnt) {
+#ifdef RT_DEBUG_PROBE
+    if (CFG::BVH) {
+        int a_id = -1, b_id = -1; f4 a_sec, b_sec;
+        const int a = CFG::SHARE ? glossy_search_shared<CFG::NODE_BUDGET>(sc, bv, lbv, probe, current, run, a_id, a_sec, ws, lws, share, cnt)
+                                 : glossy_search_bvh(sc, bv, lbv, probe, current, run, a_id, a_sec, ws, lws, cnt);
+        const int b = glossy_search_bf(sc, probe, current, run, b_id, b_sec);
+        if (run && (a != b || (a == 2 && a_id != b_id)))
+            printf("GLOSSY share %d: o %.9g %.9g %.9g d %.9g %.9g %.9g cur %d  tree %d id %d sec %.9g %.9g %.9g %.9g  loop %d id %d sec %.9g %.9g %.9g %.9g\n",
+                   (int)CFG::SHARE, probe.o.x, probe.o.y, probe.o.z, probe.d.x, probe.d.y, probe.d.z, current, a, a_id, a_sec.x, a_sec.y, a_sec.z, a_sec.w,
+                   b, b_id, b_sec.x, b_sec.y, b_sec.z, b_sec.w);
+        light_id = a_id; lsec = a_sec;
+        return a;
+    }
+#endif
     if (CFG::SHARE) return glossy_search_shared<CFG::NODE_BUDGET>(sc, bv, lbv, probe, current, run, light_id, lsec, ws, lws, share, cnt);
     if (CFG::BVH) return glossy_search_bvh(sc, bv, lbv, probe, current, run, light_id, lsec, ws, lws, cnt);
     return glossy_search_bf(sc, probe, current, run, light_id, lsec);

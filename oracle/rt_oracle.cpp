@@ -426,9 +426,15 @@ inline bool sampleLight(const Scene &sc, V3 position, V3 normal, int current, ui
 
     st.shadow_probes++;
     const int count = (int)sc.count;
+    if (orc_debug())
+        fprintf(stderr, "  shadow probe from %.9g %.9g %.9g dir %.9g %.9g %.9g max_t %.9g light %d\n", position.x,
+                position.y, position.z, probe.direction.x, probe.direction.y, probe.direction.z, max_t, light_id);
     for (int triID = 0; triID < count; triID++) {
         if (triID == current) continue;
-        if (intersectTriangleShadow(probe, sc.models[triID], max_t)) return false;
+        if (intersectTriangleShadow(probe, sc.models[triID], max_t)) {
+            if (orc_debug()) fprintf(stderr, "  shadow probe stopped by %d\n", triID);
+            return false;
+        }
     }
     const Material &material = material_at(sc, shading_at(sc, light_id).material_id);   // :379
 
@@ -458,10 +464,14 @@ inline bool sampleLightGlossy(const Scene &sc, const Frame &fr, V3 position, V3 
     for (int triID = 0; triID < count; triID++) {
         if (triID == current) continue;
         if (intersectTriangle(probe, sc.models[triID], isec)) {
+            if (orc_debug()) fprintf(stderr, "  glossy probe takes %d: %.9g %.9g %.9g %.9g\n", triID, isec.x, isec.y, isec.z, isec.w);
             if (triID < LIGHTS) lightID = triID;
             else { lightID = -1; break; }
         }
     }
+    if (orc_debug())
+        fprintf(stderr, "  glossy probe from %.9g %.9g %.9g dir %.9g %.9g %.9g light %d\n", position.x, position.y,
+                position.z, probe.direction.x, probe.direction.y, probe.direction.z, lightID);
     if (lightID < 0) {
         if (isec.z < 0.0f) light = skyColor(sc, fr, probe.direction);
         return isec.z < 0.0f;
@@ -488,6 +498,9 @@ V3 trace(const Scene &sc, const Frame &fr, Ray ray, uint32_t seed, uint32_t ligh
     for (int depth = 0; depth < MAX_RECURSION; depth++) {
         V3 sec;
         st.rays++;
+        if (orc_debug())
+            fprintf(stderr, "ray from %.9g %.9g %.9g dir %.9g %.9g %.9g\n", ray.position.x, ray.position.y, ray.position.z,
+                    ray.direction.x, ray.direction.y, ray.direction.z);
         const int current_tri = findIntersection(sc, ray, sec);
         if (current_tri < 0) {
             energy = energy + skyColor(sc, fr, ray.direction) * path;

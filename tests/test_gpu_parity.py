@@ -5,6 +5,7 @@
     device and the checker evaluate the same IEEE operation sequence), and a relative-RMSE bound
     against the checker's independent C-library back end."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -517,6 +518,89 @@ def test_random_soups(gpu_ctx, oracle_mod, tmp_path, seed):
         assert same.all(), (seed, pipeline, int((~same).sum()))
         for k in ("rays", "shadow_probes", "glossy_probes"):
             assert st[k] == wst[k], (seed, pipeline, k)
+
+
+def _flat_rays(rng, n, lo, hi):
+    """Rays with direction components of exactly zero, of both signs of zero, denormal, and tiny but normal."""
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    tiny = np.array([0.0, -0.0, 1e-39, -1e-39, 1e-30, -1e-30, 2.0 ** -70, -(2.0 ** -60)], np.float32)
+    which = rng.integers(0, 7, size=n)                     # bit k: component k is replaced; 0 leaves the ray as it is
+    for k in range(3):
+        sel = ((which >> k) & 1) == 1
+        d[sel, k] = tiny[rng.integers(0, len(tiny), size=int(sel.sum()))]
+    return o, d
+
+
+@pytest.mark.parametrize("name", ["cubes", "soup"])
+def test_axis_parallel_rays(gpu_ctx, oracle_mod, tmp_path, name):
+    # a zero direction component makes the reciprocal infinite: the box tests must still visit every candidate
+    if name == "soup":
+        from gpuraytracer_amd import host
+        base = str(tmp_path / "soup_flat")
+        _write_soup(base, 21, 1500)
+        scene = host.load_wavefront(base)
+    else:
+        scene = load_scene(name)
+    _upload(gpu_ctx, scene, constant_env())
+    o, d = _flat_rays(np.random.default_rng(5), 60000, -2.5, 2.5)
+    # origins on the coordinates of triangle corners as well: the ray then lies in the plane of a box side
+    p0 = scene[0]["position"]
+    o[:20000] = p0[np.random.default_rng(6).integers(0, len(p0), size=20000)]
+    want_ids, want_uvt = oracle_mod.OracleScene(*scene).closest_hit_batch(o, d)
+    assert (want_ids >= 0).mean() > 0.1
+    for accel in (0, 1):
+        gpu_ctx.set_option("accel", accel)
+        ids, uvt = gpu_ctx.closest_hit_batch(o, d)
+        assert np.array_equal(ids, want_ids), (accel, int((ids != want_ids).sum()))
+        assert np.array_equal(uvt.view(np.uint32), want_uvt.view(np.uint32)), accel
+
+
+@pytest.mark.parametrize("zero_row", [0, 1, 2])
+@pytest.mark.parametrize("name", ["cubes", "soup"])
+def test_axis_parallel_render(gpu_ctx, oracle_mod, tmp_path, name, zero_row):
+    # a camera matrix with a zero row: every primary ray has that direction component exactly zero, in all
+    # forms of the pipeline (resident hierarchy for the cubes, hierarchy in memory for the soup)
+    if name == "soup":
+        from gpuraytracer_amd import host
+        base = str(tmp_path / "soup_flat")
+        _write_soup(base, 22, 900)
+        scene = host.load_wavefront(base)
+        cam = camera_matrix((0.2, 0.4, -4.5), (-0.1, 0.05))
+    else:
+        scene = load_scene(name)
+        cam = camera_matrix()
+    cam = cam.copy()
+    cam[[zero_row, 4 + zero_row, 8 + zero_row]] = 0.0
+    env = gradient_env()
+    _upload(gpu_ctx, scene, env)
+    sc = oracle_mod.OracleScene(*scene)
+    sc.upload_env(env)
+    want, wst = sc.render(cam, 4242, 6, 1.0, 64, 48, 0, 4)
+    assert wst["rays"] > wst["pixel_samples"]
+    for pipeline in (1, 3, 5, 6, 7):
+        img, st = _render(gpu_ctx, 64, 48, 0, 4, recursion=6, clock=4242, pipeline=pipeline, batch=2, cam=cam)
+        same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
+        assert same.all(), (pipeline, int((~same).sum()))
+        for k in ("rays", "shadow_probes", "glossy_probes"):
+            assert st[k] == wst[k], (pipeline, k)
+
+
+@pytest.mark.parametrize("seed", [1111, 1260])
+def test_soak_findings(gpu_ctx, tmp_path, seed):
+    # scenes of tools/soak_parity.py in which one ray had a direction component of exactly zero (a primary ray in
+    # the first, a glossy probe in the second) and the hierarchy forms lost its hit
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak_parity
+    scene, cam, w, h, spp, rec, clock, batches = soak_parity.case_for(seed, str(tmp_path), _write_soup)
+    _upload(gpu_ctx, scene, gradient_env())
+    want, wst = _render(gpu_ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=3, cam=cam)
+    for pipeline in (1, 5, 7):
+        img, st = _render(gpu_ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=pipeline, cam=cam)
+        same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
+        assert same.all(), (pipeline, int((~same).sum()))
+        for k in ("rays", "shadow_probes", "glossy_probes"):
+            assert st[k] == wst[k], (pipeline, k)
 
 
 def test_irradiance_prefilter_bit_exact(gpu_ctx, oracle_mod):

@@ -1,0 +1,76 @@
+"""Soak run of the parity check on a GPU: random triangle soups of random size (the generator of the GPU tests), random
+cameras, clocks, depths and target sizes; the library's default forms against the loops over all triangles (the
+reference's own algorithm) and two other staged forms, bit for bit with equal counters; every fourth scene also against
+the CPU checker.  Prints one line per scene and a summary; exit status 1 if anything differed.
+    python tools/soak_parity.py [first seed] [number of scenes]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gpuraytracer_amd as g                     # noqa: E402
+from gpuraytracer_amd import host                # noqa: E402
+from gpuraytracer_amd.camera import camera_matrix   # noqa: E402
+from conftest import gradient_env                # noqa: E402
+
+
+def case_for(seed, tmp, write_soup=None):
+    """Everything that defines the scene and the render of one seed.  `write_soup`: the soup generator of the GPU
+    tests (the tests pass their own, so that this file does not import them a second time)."""
+    if write_soup is None:
+        import test_gpu_parity
+        write_soup = test_gpu_parity._write_soup
+    rng = np.random.default_rng(seed)
+    n_tris = int(10 ** rng.uniform(1.7, 4.5))
+    base = os.path.join(tmp, "soup%d" % seed)
+    write_soup(base, seed, n_tris)
+    scene = host.load_wavefront(base)
+    cam = camera_matrix(tuple(rng.uniform([-1, -0.5, -6], [1, 2, -3])), tuple(rng.uniform([-0.4, -0.3], [0.2, 0.3])))
+    w, h = int(rng.integers(17, 400)), int(rng.integers(9, 300))
+    spp, rec, clock = int(rng.integers(1, 7)), int(rng.integers(1, 20)), int(rng.integers(1, 2 ** 31))
+    batches = [int(rng.integers(1, 5)) for _ in range(4)]
+    return scene, cam, w, h, spp, rec, clock, batches
+
+
+def main():
+    import test_gpu_parity as T
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    ctx = g.Context(0)
+    bad = 0
+    tmp = tempfile.mkdtemp()
+    env = gradient_env()
+    for seed in range(first, first + count):
+        scene, cam, w, h, spp, rec, clock, batches = case_for(seed, tmp)
+        T._upload(ctx, scene, env)
+        want, wst = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=3, batch=batches[0], cam=cam)
+        line = "seed %d: %d tris %dx%d spp %d rec %d rays %d" % (seed, len(scene[0]), w, h, spp, rec, wst["rays"])
+        for k, form in enumerate((1, 5, 7)):
+            img, st = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=form, batch=batches[1 + k], cam=cam)
+            same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
+            ok = same.all() and all(st[key] == wst[key] for key in ("rays", "shadow_probes", "glossy_probes"))
+            if not ok:
+                bad += 1
+                line += "  FORM %d DIFFERS (%d values)" % (form, int((~same).sum()))
+        if seed % 4 == 0 and len(scene[0]) * w * h * spp < 4e9:
+            from oracle import oracle
+            sc = oracle.OracleScene(*scene)
+            sc.upload_env(env)
+            ref, rst = sc.render(cam, clock, rec, 1.0, w, h, 0, spp)
+            same = (ref.view(np.uint32) == want.view(np.uint32)) | (np.isnan(ref) & np.isnan(want))
+            if not (same.all() and rst["rays"] == wst["rays"]):
+                bad += 1
+                line += "  CHECKER DIFFERS (%d values)" % int((~same).sum())
+            else:
+                line += "  checker ok"
+        print(line, flush=True)
+    print("%d scenes, %d differences" % (count, bad))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
