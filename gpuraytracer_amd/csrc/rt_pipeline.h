@@ -267,12 +267,14 @@ RT_DEV int glossy_search_cfg(const DScene &sc, const DBvh &bv, const DBvh &lbv, 
 // wave can never emit more entries than it consumed, so a region of ceil(chunks / PIPE_WAVES) * 64
 // entries always suffices.  With one atomic per wave and queue on three shared counters the shade
 // stage spent 87 % of its time waiting (2.2 ms for 8.3 M paths); the regions took that away.
+struct Radiance { float x, y, z; };
 struct PipeBuffers {
     float4 *xa[2], *xb[2], *xc[2];              // extend queues (ping-pong): path records
     uint4 *xd[2];
     float4 *pa, *pb, *pc, *p0, *p1, *p2;        // probe queue: shadow records from the front of a region, glossy from its back
     uint4 *pd;
-    float4 *h0, *energy, *kd, *ks;
+    float4 *h0, *kd, *ks;
+    Radiance *energy;            // 12 bytes per path: this plane is written once and read once by every path of a pass
     uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
     uint32_t *work;                             // [N_RUNS] chunks of the depth-0 kernel handed out so far, per part of the target
     uint32_t region_cap;
@@ -308,7 +310,7 @@ RT_DEV void store_path_rec(const PipeBuffers &b, int q, size_t i, const PathStat
 RT_DEV void load_probe_path(const PipeBuffers &b, size_t i, PathState &ps) { unpack_path(b.pa[i], b.pb[i], b.pc[i], ps); }
 // A path that has ended leaves its radiance for the resolve stage.
 RT_DEV void finish_path(const PipeBuffers &b, uint32_t id, const PathState &ps) {
-    b.energy[id] = make_float4(ps.energy.x, ps.energy.y, ps.energy.z, 0.0f);
+    b.energy[id] = Radiance{ps.energy.x, ps.energy.y, ps.energy.z};
 }
 
 // Even shares of a queue for the tail kernel.  A stage reads what the stage before left in the 4096 regions, and
@@ -1063,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restri
     const uint32_t local = tile_number(tx >> 3, ty >> 3, tiles_x, tiles_y) * 64u + (ty & 7u) * 8u + (tx & 7u);
     float4 s = sum[pix];
     for (uint32_t k = 0; k < n_slots; k++) {
-        const float4 e = b.energy[(size_t)k * paths_per_sample + local];
+        const Radiance e = b.energy[(size_t)k * paths_per_sample + local];
         s.x += e.x; s.y += e.y; s.z += e.z;
     }
     sum[pix] = s;
@@ -1125,7 +1127,7 @@ struct Pipeline {
     // Device memory of the queues of a pass of `paths` pixel-samples.
     static size_t queue_bytes_for(size_t paths, bool with_h0) {
         const size_t qn = (size_t)region_cap_for(paths) * PIPE_WAVES;
-        return qn * (2 * 64 + 112 + (with_h0 ? 16 : 0)) + paths * 48;
+        return qn * (2 * 64 + 112 + (with_h0 ? 16 : 0)) + paths * (sizeof(Radiance) + 32);
     }
     size_t queue_bytes() const { return cap_paths ? queue_bytes_for(cap_paths, have_h0) : 0; }
 
@@ -1161,7 +1163,7 @@ struct Pipeline {
             PIPE_ALLOC(buf.p1, sizeof(float4) * qn);
             PIPE_ALLOC(buf.p2, sizeof(float4) * qn);
             if (need_h0) PIPE_ALLOC(buf.h0, sizeof(float4) * qn);
-            PIPE_ALLOC(buf.energy, sizeof(float4) * want);
+            PIPE_ALLOC(buf.energy, sizeof(Radiance) * want);
             PIPE_ALLOC(buf.kd, sizeof(float4) * want);
             PIPE_ALLOC(buf.ks, sizeof(float4) * want);
             cap_paths = want;
