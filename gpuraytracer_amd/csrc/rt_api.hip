@@ -65,6 +65,7 @@ struct rt_context {
     // options
     int pipeline = 1;
     int batch_samples = 32;
+    int queue_rounds = 3;      // the path queues hold 1/queue_rounds of a pass's paths (Pipeline::rounds)
     int profiling = 0;
     int share = 1;             // lanes of a wave share the any-hit searches of its probes (anyhit_shared)
     int staged_depths = 2;     // bounces after the first that run as staged kernels before the tail kernel takes the rest; -1: all
@@ -607,19 +608,21 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
     form.refill = acc && (ctx->refill < 0 ? ctx->count >= REFILL_AUTO_MIN : ctx->refill != 0);
     form.staged_depths = ctx->staged_depths;
     if (ctx->pipeline != 0) {
-        // The queues of a pass are sized for the case that every path survives every bounce; fewer samples per pass if
-        // that does not fit the free device memory (the image does not depend on the pass size).
+        // The queues of a pass hold 1/queue_rounds of the case that every path survives every bounce (a pass that needs
+        // more takes more rounds); fewer samples per pass if that does not fit the free device memory (the image does
+        // not depend on the pass size).
         const size_t pps = (size_t)(((ctx->width + 7u) >> 3) * ((ctx->height + 7u) >> 3)) * 64u;
         const bool h0 = form.refill;
-        if (pps * chunk_max > ctx->pipe.cap_paths || (h0 && !ctx->pipe.have_h0)) {
+        const uint32_t rounds = (uint32_t)ctx->queue_rounds;
+        if (pps * chunk_max > ctx->pipe.cap_paths || (h0 && !ctx->pipe.have_h0) || rounds != ctx->pipe.rounds) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 const size_t have = ctx->pipe.queue_bytes();      // released before the larger allocation is made
-                while (chunk_max > 1u && (double)Pipeline::queue_bytes_for(pps * chunk_max, h0) > 0.9 * (double)(free_b + have))
+                while (chunk_max > 1u && (double)Pipeline::queue_bytes_for(pps * chunk_max, h0, rounds) > 0.9 * (double)(free_b + have))
                     chunk_max = (chunk_max + 1u) / 2u;
             }
             const char *msg = nullptr;
-            const hipError_t e = ctx->pipe.ensure(pps * chunk_max, h0, &msg);
+            const hipError_t e = ctx->pipe.ensure(pps * chunk_max, h0, rounds, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s", msg ? msg : "queues",
                             hipGetErrorString(e));
@@ -791,6 +794,9 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
     unsigned long long ws[WSTAT_SLOTS];
     HIP_TRY(ctx, ctx->pipe.read_wstats(ws));
+    bool lost = false;
+    HIP_TRY(ctx, ctx->pipe.read_lost(&lost));
+    if (lost) return fail(ctx, RT_ERR_DEVICE, "rt_get_stats: a pass ended with camera paths not rendered (queue_rounds)");
     ds.pixel_samples += ws[WSTAT_PATHS];
     ds.rays += ws[WSTAT_RAYS];
     ds.shadow_probes += ws[WSTAT_SHADOW];
@@ -838,6 +844,9 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "batch_samples")) {
         if (value < 1 || value > MAX_BATCH) return fail(ctx, RT_ERR_LIMIT, "batch_samples must be in [1, %d]", MAX_BATCH);
         ctx->batch_samples = (int)value;
+    } else if (!strcmp(name, "queue_rounds")) {
+        if (value < 1 || value > (int64_t)MAX_ROUNDS) return fail(ctx, RT_ERR_LIMIT, "queue_rounds must be in [1, %d]", (int)MAX_ROUNDS);
+        ctx->queue_rounds = (int)value;
     } else if (!strcmp(name, "accel")) {
         if (value < -1 || value > 1) return fail(ctx, RT_ERR_INVALID, "accel must be -1 (auto), 0 or 1");
         ctx->accel = (int)value;

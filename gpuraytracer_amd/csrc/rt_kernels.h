@@ -21,7 +21,7 @@ struct DStats {
 // (raytracer.glsl:595-598).  The coin of a bounce (raytracer.glsl:553: unitFloat(light_seed) < 0.5, drawn once per
 // bounce from a stream all pixels of a sample share) is recomputed from light_seed where it is needed.
 #ifndef RT_MAX_BATCH
-#define RT_MAX_BATCH 128
+#define RT_MAX_BATCH 256
 #endif
 constexpr int MAX_BATCH = RT_MAX_BATCH;
 struct PassTables {

@@ -97,6 +97,18 @@ constexpr uint32_t N_XCD = 8;
 constexpr uint32_t RUNS_PER_XCD = RT_RUNS_PER_XCD, N_RUNS = N_XCD * RUNS_PER_XCD;
 constexpr uint32_t CHUNK_BLOCK = RT_CHUNK_BLOCK;        // consecutive chunks that stay in one run (one tile's samples at 64 per pass)
 constexpr uint32_t DYNAMIC_SHARE = RT_DYNAMIC_SHARE;    // 1/DYNAMIC_SHARE of the rounds is handed out as waves become free
+// Rounds of a pass.  The queue regions are sized for 1/rounds of the paths a wave may have to hand on (every path of
+// every chunk it renders, if all of them survive).  The launch sequence of a pass is repeated `rounds` times: a wave of
+// the depth-0 kernel stops taking chunks when its region cannot hold another one whole, and carries on in the next
+// round, after the deeper stages have emptied the regions.  A region holds one chunk more than its share, so `rounds`
+// rounds always get through the pass; usually (a fifth of the camera paths goes on in the bundled scenes) the first
+// round does, raises no flag, and the kernels of the later rounds return at once.
+constexpr uint32_t MAX_ROUNDS = 8;
+RT_DEV uint32_t *more_flags(uint32_t *work) { return work + N_RUNS; }
+// True when these launches have nothing to do: a later round of a pass whose earlier rounds got through.
+RT_DEV bool round_is_idle(const uint32_t *work, uint32_t round) {
+    return round > 0u && __builtin_nontemporal_load(work + N_RUNS + (round - 1u)) == 0u;
+}
 // The run a wave works on as its `part`-th: its own, then the others of its XCD, then those of the other XCDs.
 RT_DEV uint32_t run_of_part(uint32_t home, uint32_t part) {
     const uint32_t xcd = home / RUNS_PER_XCD, sub = home % RUNS_PER_XCD;
@@ -276,8 +288,12 @@ struct PipeBuffers {
     float4 *h0, *kd, *ks;
     Radiance *energy;            // 12 bytes per path: this plane is written once and read once by every path of a pass
     uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
-    uint32_t *work;                             // [N_RUNS] chunks of the depth-0 kernel handed out so far, per part of the target
+    uint32_t *work;                             // [N_RUNS] chunks of the depth-0 kernel handed out so far, per part of the target;
+                                                // then [MAX_ROUNDS + 1] `more` flags: more[r] != 0 = round r of the pass left chunks undone
+    uint32_t *resume;                           // [PIPE_WAVES] the fixed share of each wave: how far the rounds so far have come;
+                                                // then one word that is set if the last round of a pass ever left chunks undone
     uint32_t region_cap;
+    uint32_t round, rounds;                     // round of the pass these launches belong to, and how many it has (see MAX_ROUNDS)
     unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
 };
 
@@ -489,6 +505,7 @@ RT_DEV bool first_path(const DFrame &fr, uint32_t sample, uint32_t in_sample, ui
 template <class CFG>
 __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
                                                           PassTables tab, uint32_t paths_per_sample, int max_depth) {
+    if (round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
     const uint32_t total = b.n_ext[q_in][wave];
     const size_t region = (size_t)wave * b.region_cap;
@@ -529,10 +546,13 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
 // coin (raytracer.glsl:553: light_seed depends on SAMPLE and depth only) and run the same kind of probe, from
 // neighbouring surface points: the probe can run in place with full lanes, and the probe records (112 bytes
 // per path written and read back) are never made.  Deeper bounces mix samples in a wave and keep the queues.
-template <class CFG>
+// LATER: the instantiation launched for the rounds of a pass after the first (see MAX_ROUNDS), the same code under a
+// name of its own, so that a profile tells the launches that render a pass from those that usually return at once.
+template <class CFG, bool LATER>
 __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void k_first(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
                                                                               PassTables tab, uint32_t paths_per_sample,
                                                                               int max_depth) {
+    if (LATER && round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
     const uint32_t total = paths_per_sample * tab.n;
     const uint32_t tiles_x = (fr.width + 7u) >> 3;
@@ -575,8 +595,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     const uint32_t n_blocks = n_chunks > fixed_chunks ? (n_chunks - fixed_chunks + CHUNK_BLOCK - 1u) / CHUNK_BLOCK : 0u;
     const uint32_t home = (blockIdx.x % N_XCD) * RUNS_PER_XCD + (blockIdx.x / N_XCD) % RUNS_PER_XCD;
     const uint32_t first = first_chunk_of_wave();
-    uint32_t round = 0, part = 0, run_x = home, run_count = 0, ahead = 0;
+    uint32_t round = LATER ? b.resume[wave] : 0u, part = 0, run_x = home, run_count = 0, ahead = 0;
     bool have_ahead = false;
+    bool stalled = false;      // this wave's region is full and chunks may be left: the pass needs another round
     auto enter_part = [&]() {
         run_x = run_of_part(home, part);
         run_count = n_blocks > run_x ? ((n_blocks - run_x + N_RUNS - 1u) / N_RUNS) * CHUNK_BLOCK : 0u;
@@ -586,10 +607,13 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         if (lane == 0) c = atomicAdd(&b.work[run_x], 1u);
         return c;
     };
+    // a run that is used up is seen with a plain read; only a run that has chunks left costs an atomic operation
+    auto used_up = [&]() -> bool { return __builtin_nontemporal_load(&b.work[run_x]) >= run_count; };
     enter_part();
     for (;;) {
         uint32_t chunk;
         if (round < fixed_rounds) {
+            if (fill_next + 64u > b.region_cap) { stalled = true; break; }
             chunk = round * (uint32_t)PIPE_WAVES + first;
             round++;
         } else {
@@ -597,7 +621,12 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
             if (have_ahead) {
                 c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
             } else {
-                if (fill_next + 64u > b.region_cap) break;        // this wave's region cannot take another chunk whole
+                if (used_up()) {
+                    if (++part == N_RUNS) break;
+                    enter_part();
+                    continue;
+                }
+                if (fill_next + 64u > b.region_cap) { stalled = true; break; }        // this wave's region cannot take another chunk whole
                 c = (uint32_t)__builtin_amdgcn_readfirstlane((int)take());
             }
             have_ahead = false;
@@ -694,6 +723,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         b.n_shadow[wave] = 0;
         b.n_glossy[wave] = 0;
         b.n_ext[1][wave] = fill_next;
+        b.resume[wave] = round;
+        if (stalled) more_flags(b.work)[b.round] = 1u;
+        if (stalled && b.round + 1u == b.rounds) b.resume[PIPE_WAVES] = 1u;      // cannot happen by the sizing of the regions
     }
     wstat_add(b, WSTAT_PATHS, n_paths);
     wstat_add(b, WSTAT_RAYS, n_paths);
@@ -727,6 +759,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
 template <class CFG>
 __global__ __launch_bounds__(64 * WG_WAVES, RT_MIN_WAVES) void k_tail(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b, int depth0,
                                                            int q_in, PassTables tab, uint32_t paths_per_sample, int max_depth) {
+    if (round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
     RT_TRAVERSAL_LDS(CFG);
     typename CFG::WS ws, lws;
@@ -830,6 +863,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, RT_MIN_WAVES) void k_tail(DScene sc,
 // Shading of the paths whose hit records the lane-refill form of the extend stage has left in h0.
 __global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in, PassTables tab,
                                                          uint32_t paths_per_sample, int max_depth) {
+    if (round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
     const uint32_t total = b.n_ext[q_in][wave];
     const size_t region = (size_t)wave * b.region_cap;
@@ -905,6 +939,7 @@ RT_DEV bool retire_glossy(const DScene &sc, const DFrame &fr, const PipeBuffers 
 template <class CFG>
 __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_probe_shadow(DScene sc, DBvh bv, PipeBuffers b, int depth, int q_in,
                                                                 int max_depth) {
+    if (round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
     RT_TRAVERSAL_LDS(CFG);
     typename CFG::WS ws, lws;
@@ -940,6 +975,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
 template <class CFG>
 __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_probe_glossy(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
                                                                 int depth, int q_in, int max_depth) {
+    if (round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
     RT_TRAVERSAL_LDS(CFG);
     typename CFG::WS ws, lws;
@@ -1007,6 +1043,7 @@ RT_DEV bool refill_take(uint32_t total, uint32_t &next, bool busy, uint32_t &k) 
 // record and k_shade does the shading with full waves.
 template <class CFG>
 __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_extend_refill(DScene sc, DBvh bv, PipeBuffers b, int q_in) {
+    if (round_is_idle(b.work, b.round)) return;
     const uint32_t wave = wave_index();
     RT_TRAVERSAL_LDS(CFG);
     typename CFG::WS ws, lws;
@@ -1085,10 +1122,11 @@ struct Pipeline {
     PipeBuffers buf = {};
     size_t cap_paths = 0;
     bool have_h0 = false;
+    uint32_t rounds = 1;           // the queues are sized for 1/rounds of cap_paths (see MAX_ROUNDS)
     // Profiling: events are recorded around every stage launch and turned into times lazily
     // (collect_times), so that the timed region carries no extra synchronisation.
     std::vector<hipEvent_t> events;
-    std::vector<int> kinds;        // interval i = [event i, event i+1]: 0 extend, 3 extend at depth 0, 1 probes, 2 shade, -1 not counted
+    std::vector<int> kinds;        // interval i = [event i, event i+1]: 0 extend, 3 extend at depth 0, 1 probes, 2 shade, -1 not counted (4-6: see collect_times)
     size_t ev_used = 0;
 
     std::vector<void **> path_buffers() {
@@ -1099,7 +1137,7 @@ struct Pipeline {
     }
     std::vector<void **> counter_buffers() {
         return {(void **)&buf.wstats, (void **)&buf.n_ext[0], (void **)&buf.n_ext[1], (void **)&buf.n_shadow, (void **)&buf.n_glossy,
-                (void **)&buf.work};
+                (void **)&buf.work, (void **)&buf.resume};
     }
 
     void free_paths() {
@@ -1118,20 +1156,22 @@ struct Pipeline {
 
     // From depth 1 on a wave can never emit more entries than it consumed.  The depth-0 kernel hands out its chunks
     // as waves become free and a wave stops taking chunks when its region cannot hold another one whole, so with one
-    // chunk of slack per region, (ceil(chunks / PIPE_WAVES) + 1) * 64 entries, the regions that still have room can
-    // always hold what is left.
-    static uint32_t region_cap_for(size_t paths) {
+    // chunk of slack per region the regions that still have room can always hold what is left: a region holds
+    // (ceil(ceil(chunks / PIPE_WAVES) / rounds) + 1) * 64 entries, and `rounds` rounds of the launch sequence get
+    // through the pass even if every path survives (each round a wave renders at least ceil(share / rounds) + 1 chunks).
+    static uint32_t region_cap_for(size_t paths, uint32_t rounds) {
         const size_t chunks = (paths + 63) / 64;
-        return (uint32_t)(((chunks + PIPE_WAVES - 1) / PIPE_WAVES + 1) * 64);
+        const size_t share = (chunks + PIPE_WAVES - 1) / PIPE_WAVES;
+        return (uint32_t)(((share + rounds - 1) / rounds + 1) * 64);
     }
     // Device memory of the queues of a pass of `paths` pixel-samples.
-    static size_t queue_bytes_for(size_t paths, bool with_h0) {
-        const size_t qn = (size_t)region_cap_for(paths) * PIPE_WAVES;
+    static size_t queue_bytes_for(size_t paths, bool with_h0, uint32_t rounds) {
+        const size_t qn = (size_t)region_cap_for(paths, rounds) * PIPE_WAVES;
         return qn * (2 * 64 + 112 + (with_h0 ? 16 : 0)) + paths * (sizeof(Radiance) + 32);
     }
-    size_t queue_bytes() const { return cap_paths ? queue_bytes_for(cap_paths, have_h0) : 0; }
+    size_t queue_bytes() const { return cap_paths ? queue_bytes_for(cap_paths, have_h0, rounds) : 0; }
 
-    hipError_t ensure(size_t paths, bool need_h0, const char **what) {
+    hipError_t ensure(size_t paths, bool need_h0, uint32_t want_rounds, const char **what) {
         hipError_t e = hipSuccess;
 #define PIPE_ALLOC(ptr, bytes) do { *what = #ptr; e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) goto failed; } while (0)
         if (!buf.wstats) {
@@ -1143,12 +1183,17 @@ struct Pipeline {
             PIPE_ALLOC(buf.n_ext[1], sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_shadow, sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_glossy, sizeof(uint32_t) * PIPE_WAVES);
-            PIPE_ALLOC(buf.work, sizeof(uint32_t) * N_RUNS);
+            PIPE_ALLOC(buf.work, sizeof(uint32_t) * (N_RUNS + MAX_ROUNDS + 1));
+            PIPE_ALLOC(buf.resume, sizeof(uint32_t) * (PIPE_WAVES + 1));
+            *what = "memset resume";
+            e = hipMemset(buf.resume, 0, sizeof(uint32_t) * (PIPE_WAVES + 1));
+            if (e != hipSuccess) goto failed;
         }
-        if (paths > cap_paths || (need_h0 && !have_h0)) {
-            const size_t want = paths > cap_paths ? paths : cap_paths;
+        if (paths > cap_paths || (need_h0 && !have_h0) || want_rounds != rounds) {
+            const size_t want = (paths > cap_paths || want_rounds != rounds) ? paths : cap_paths;
             free_paths();
-            const size_t qn = (size_t)region_cap_for(want) * PIPE_WAVES;      // queue planes hold PIPE_WAVES regions
+            rounds = want_rounds;
+            const size_t qn = (size_t)region_cap_for(want, rounds) * PIPE_WAVES;      // queue planes hold PIPE_WAVES regions
             for (int k = 0; k < 2; k++) {
                 PIPE_ALLOC(buf.xa[k], sizeof(float4) * qn);
                 PIPE_ALLOC(buf.xb[k], sizeof(float4) * qn);
@@ -1189,15 +1234,17 @@ struct Pipeline {
                 e = hipEventElapsedTime(&ms, events[i], events[i + 1]);
                 if (e != hipSuccess) break;
                 host_stats->trace_ms += ms;
-                if (kinds[i] == 0 || kinds[i] == 3) {
+                // 4, 5, 6: the launches of kinds 3, 0, 1 in the rounds of a pass after the first
+                if (kinds[i] == 0 || kinds[i] == 3 || kinds[i] == 4 || kinds[i] == 5) {
                     host_stats->extend_ms += ms;
-                    host_stats->extend_launches++;
-                    if (kinds[i] == 3) { host_stats->extend0_ms += ms; host_stats->extend0_launches++; }
+                    if (kinds[i] == 0 || kinds[i] == 3) host_stats->extend_launches++;
+                    if (kinds[i] == 3 || kinds[i] == 4) host_stats->extend0_ms += ms;
+                    if (kinds[i] == 3) host_stats->extend0_launches++;
                 } else if (kinds[i] == 2) {
                     host_stats->shade_ms += ms;
                 } else {
                     host_stats->probe_ms += ms;
-                    host_stats->probe_launches += 2;
+                    if (kinds[i] == 1) host_stats->probe_launches += 2;
                 }
             }
         }
@@ -1215,6 +1262,15 @@ struct Pipeline {
         if (e != hipSuccess) return e;
         for (size_t i = 0; i < h.size(); i++) out[i % WSTAT_SLOTS] += h[i];
         return hipSuccess;
+    }
+    // True if a pass ever ended with chunks undone (the sizing of the regions rules it out; checked with the statistics).
+    hipError_t read_lost(bool *lost) {
+        *lost = false;
+        if (!buf.resume) return hipSuccess;
+        uint32_t v = 0;
+        const hipError_t e = hipMemcpy(&v, buf.resume + PIPE_WAVES, sizeof(v), hipMemcpyDeviceToHost);
+        *lost = v != 0;
+        return e;
     }
     hipError_t reset_wstats(hipStream_t stream) {
         if (!buf.wstats) return hipSuccess;
@@ -1254,37 +1310,43 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
     };
     const dim3 grid(PIPE_WAVES / WG_WAVES), block(64 * WG_WAVES);
     // depth 0 runs its probes in place (k_first): queue 0 is never read and the first queue is 1
-    PIPE_TRY(hipMemsetAsync(buf.work, 0, sizeof(uint32_t) * N_RUNS, stream));
-    PIPE_TRY(stamp(3));
-    hipLaunchKernelGGL(k_first<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
-    PIPE_TRY(hipGetLastError());
-    PIPE_TRY(stamp(-1));
-    int q_in = 1;
+    PIPE_TRY(hipMemsetAsync(buf.work, 0, sizeof(uint32_t) * (N_RUNS + MAX_ROUNDS + 1), stream));
     const int staged_end = form.staged_depths < 0 ? max_depth : (1 + form.staged_depths < max_depth ? 1 + form.staged_depths : max_depth);
-    for (int depth = 1; depth < staged_end; depth++) {
-        PIPE_TRY(stamp(0));
-        if (CFG::BVH && form.refill) {
-            hipLaunchKernelGGL(k_extend_refill<CFG>, grid, block, 0, stream, sc, bvh, buf, q_in);
+    for (uint32_t round = 0; round < rounds; round++) {
+        // launches of the rounds after the first are timed with the others but not counted as launches (most return at once)
+        buf.round = round;
+        buf.rounds = rounds;
+        PIPE_TRY(stamp(round == 0 ? 3 : 4));
+        if (round == 0) hipLaunchKernelGGL((k_first<CFG, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
+        else hipLaunchKernelGGL((k_first<CFG, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
+        PIPE_TRY(hipGetLastError());
+        PIPE_TRY(stamp(-1));
+        int q_in = 1;
+        for (int depth = 1; depth < staged_end; depth++) {
+            PIPE_TRY(stamp(round == 0 ? 0 : 5));
+            if (CFG::BVH && form.refill) {
+                hipLaunchKernelGGL(k_extend_refill<CFG>, grid, block, 0, stream, sc, bvh, buf, q_in);
+                PIPE_TRY(hipGetLastError());
+                PIPE_TRY(stamp(2));
+                hipLaunchKernelGGL(k_shade, grid, block, 0, stream, sc, fr, buf, depth, q_in, tab, pps, max_depth);
+            } else {
+                hipLaunchKernelGGL(k_extend<CFG>, grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, tab, pps, max_depth);
+            }
             PIPE_TRY(hipGetLastError());
-            PIPE_TRY(stamp(2));
-            hipLaunchKernelGGL(k_shade, grid, block, 0, stream, sc, fr, buf, depth, q_in, tab, pps, max_depth);
-        } else {
-            hipLaunchKernelGGL(k_extend<CFG>, grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, tab, pps, max_depth);
+            PIPE_TRY(stamp(round == 0 ? 1 : 6));
+            hipLaunchKernelGGL(k_probe_shadow<CFG>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
+            PIPE_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_probe_glossy<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
+            PIPE_TRY(hipGetLastError());
+            PIPE_TRY(stamp(-1));
+            q_in ^= 1;
         }
-        PIPE_TRY(hipGetLastError());
-        PIPE_TRY(stamp(1));
-        hipLaunchKernelGGL(k_probe_shadow<CFG>, grid, block, 0, stream, sc, bvh, buf, depth, q_in, max_depth);
-        PIPE_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_probe_glossy<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, depth, q_in, max_depth);
-        PIPE_TRY(hipGetLastError());
-        PIPE_TRY(stamp(-1));
-        q_in ^= 1;
-    }
-    if (staged_end < max_depth) {
-        PIPE_TRY(stamp(0));
-        hipLaunchKernelGGL(k_tail<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, staged_end, q_in, tab, pps, max_depth);
-        PIPE_TRY(hipGetLastError());
-        PIPE_TRY(stamp(-1));
+        if (staged_end < max_depth) {
+            PIPE_TRY(stamp(round == 0 ? 0 : 5));
+            hipLaunchKernelGGL(k_tail<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, staged_end, q_in, tab, pps, max_depth);
+            PIPE_TRY(hipGetLastError());
+            PIPE_TRY(stamp(-1));
+        }
     }
     hipLaunchKernelGGL(k_resolve, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
                        fr.height, pps, tab.n);
@@ -1300,7 +1362,7 @@ inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &l
     const size_t paths = (size_t)tiles * 64u * (size_t)tab.n;
     if (paths > 0xFFFFFFF0ull) { *what = "batch has more than 2^32 paths"; return hipErrorInvalidValue; }
     if (paths > cap_paths || (form.bvh && form.refill && !have_h0)) { *what = "queues not sized for this pass"; return hipErrorInvalidValue; }
-    buf.region_cap = region_cap_for(cap_paths);
+    buf.region_cap = region_cap_for(cap_paths, rounds);
 #define RUN_AS(B, S, R) return launch_pass<KernelCfg<B, S, R>>(sc, bvh, light_bvh, fr, sum, tab, stream, profiling, form, host_stats, what)
     if (!form.bvh) RUN_AS(false, 0, false);
     if (form.resident) { if (form.share) RUN_AS(true, 1, true); RUN_AS(true, 0, true); }

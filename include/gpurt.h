@@ -193,8 +193,13 @@ int rt_reset_stats(rt_context *ctx);
 /* Tuning knobs; unknown names return RT_ERR_INVALID.  None of them changes a result.
  *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
  *                   1 = staged kernels over compacted ray queues (default)
- *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 128; the queues of a pass
- *                   take about 290 bytes of device memory per pixel and sample, rt_stats.queue_bytes tells)
+ *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 256; the queues of a pass
+ *                   take about 44 + 240 / queue_rounds bytes of device memory per pixel and sample,
+ *                   rt_stats.queue_bytes tells)
+ *   "queue_rounds"  n in [1, 8] (default 3): the path queues hold 1/n of the paths a pass would hand on if every path
+ *                   survived every bounce; a pass whose survivors do not fit takes up to n rounds of its launch
+ *                   sequence (about a fifth of the camera paths goes on in the reference's bundled scenes: one round;
+ *                   a closed bright room needs them all, and 1 then spares the repeated launches)
  *   "accel"         -1 = bounding-volume hierarchy for scenes of 64 triangles or more (default; scenes with a triangle
  *                   whose |cross(u, v)| is below 2^-40 keep the loops: the reference's depth comparison underflows
  *                   there and the later index wins whatever the depths, which only the loops reproduce),

@@ -34,7 +34,9 @@ def _upload(ctx, scene, env):
 FORMS = [0, 1, 2, 3, 4, 5, 6, 7, 8]
 
 
-def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM, exposure=1.0):
+def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM, exposure=1.0,
+            rounds=3):
+    ctx.set_option("queue_rounds", rounds)
     ctx.set_option("accel", 0 if pipeline in (3, 8) else 1)
     ctx.set_option("refill", 1 if pipeline == 4 else (-1 if pipeline == 1 else 0))
     ctx.set_option("staged_depths", -1 if pipeline in (2, 8) else (0 if pipeline == 5 else 2))
@@ -217,6 +219,26 @@ def test_full_size_forms_agree(gpu_ctx, oracle_mod, cubes):
     want, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 1920, 1080, 0, 1)
     one, _ = _render(gpu_ctx, 1920, 1080, 0, 1)
     assert np.array_equal(one, want)
+
+
+@pytest.mark.parametrize("name", ["cubes", "box"])
+def test_queue_rounds_agree(gpu_ctx, name):
+    # The queue regions hold 1/queue_rounds of what a pass may have to hand on, and a pass whose survivors do not fit
+    # takes further rounds of the launch sequence.  At 1920 x 1080 with 8 samples a wave's share is 64 chunks; with 8
+    # rounds a region holds 9 chunks' worth of paths, fewer than survive (checked below), so the later rounds have
+    # work to do: same sums and counters as with queues for the whole pass, bit for bit.  `box` is a closed room.
+    scene = load_scene(name)
+    _upload(gpu_ctx, scene, constant_env())
+    for pipeline in (1, 4, 5):
+        want, wst = _render(gpu_ctx, 1920, 1080, 0, 8, pipeline=pipeline, batch=8, rounds=1)
+        for rounds in (2, 8):
+            img, st = _render(gpu_ctx, 1920, 1080, 0, 8, pipeline=pipeline, batch=8, rounds=rounds)
+            assert np.array_equal(img, want, equal_nan=True), (pipeline, rounds)
+            for k in ("pixel_samples", "rays", "shadow_probes", "glossy_probes", "depth1_paths"):
+                assert st[k] == wst[k], (k, pipeline, rounds)
+            assert st["queue_bytes"] < wst["queue_bytes"]
+        chunks_per_wave = -(-(240 * 135 * 8) // 4096)
+        assert st["depth1_paths"] > 4096 * (-(-chunks_per_wave // 8) + 1) * 64      # one round of 8 could not hold them
 
 
 def test_obiwan_depth16_bit_exact(gpu_ctx, oracle_mod, obiwan):
