@@ -223,6 +223,15 @@ struct TravState {
     int node, sp;
     bool run;
 };
+// The bottom entry of every stack is a leaf of no triangles: a lane that has nothing left to visit pops it like any
+// other entry and leaves the node loop with it, so the loop needs no "is the stack empty" test and no per-lane
+// "still running" bookkeeping (a compare, a select and four scalar operations per node step).  trav_begin puts it there.
+constexpr int STACK_BOTTOM = -1;          // ~STACK_BOTTOM = leaf code 0: first slot 0, no triangles
+template <class WS>
+RT_DEV void trav_begin(const WS &ws, TravState &ts, bool run) {
+    ws.stack[0] = STACK_BOTTOM;
+    ts.node = 0; ts.sp = 1; ts.run = run;
+}
 
 // Advances every running lane of the wave.  `leaf(slot)` is called for every triangle slot of every leaf whose
 // box the ray enters within t_limit(); it returns false to stop that lane's traversal (any-hit found).
@@ -244,7 +253,7 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
         if (running == 0ull || (!at_least_one && 64 - (int)__popcll(running) >= stop_at)) break;
         // a divergent loop: lanes leave as they reach a leaf or finish, and the wave goes on when none is left
         int budget = node_budget;
-        while (run && node >= 0 && (!BUDGETED || budget-- > 0)) {
+        while (run && node >= 0 && (!BUDGETED || budget-- > 0)) {      // `run` does not change in this loop
             float in0, out0, in1, out1;
             int c0, c1;
             cnt.nodes += bvh_count_step();
@@ -287,14 +296,15 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
             const bool both = __builtin_amdgcn_inverse_ballot_w64(both_m);
             // the child to descend into: the nearer one of two, or the only one entered
             const int near = __builtin_amdgcn_inverse_ballot_w64(m0 & (first0 | ~m1)) ? c0 : c1;
-            if (both) stack[64 * sp] = __builtin_amdgcn_inverse_ballot_w64(first0) ? c1 : c0;
+            // the farther child goes on the stack if both are entered; stored in any case (slot sp is free), which
+            // spares the step a branch
+            stack[64 * sp] = __builtin_amdgcn_inverse_ballot_w64(first0) ? c1 : c0;
             sp += both ? 1 : 0;
-            const unsigned long long pop_m = __builtin_amdgcn_ballot_w64(sp > 0) & ~any_m;
-            const bool pop = __builtin_amdgcn_inverse_ballot_w64(pop_m);
+            // neither child entered: on to the top of the stack (at the bottom: the empty leaf)
+            const bool pop = __builtin_amdgcn_inverse_ballot_w64(~any_m);
             sp -= pop ? 1 : 0;
             int next = near;
             if (pop) next = stack[64 * sp];
-            run = __builtin_amdgcn_inverse_ballot_w64(any_m | pop_m);
             node = next;
         }
         if (run && (!BUDGETED || node < 0)) {      // a leaf
@@ -305,7 +315,7 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
                 cnt.tris += bvh_count_step();
                 if (go_on) go_on = leaf(first + k);
             }
-            if (go_on && sp > 0) {
+            if (go_on && sp > 1) {
                 sp--;
                 node = stack[64 * sp];
             } else {
@@ -323,7 +333,7 @@ template <class WS, typename LeafFn, typename LimitFn>
 RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const WS &ws, LeafFn leaf, LimitFn t_limit,
                          BvhCounters &cnt) {
     TravState ts;
-    ts.node = 0; ts.sp = 0; ts.run = active;
+    trav_begin(ws, ts, active);
     bvh_advance(bv, br, ws, ts, 65, leaf, t_limit, cnt);
 }
 
@@ -365,11 +375,10 @@ RT_DEV void closest_fold_reset(ClosestFold &cf, float w_init) {
     cf.n_near = 0;
     cf.st.x = 0.0f; cf.st.y = 0.0f; cf.st.z = -1.0f; cf.st.w = w_init;
 }
-// Tests the triangle of leaf slot `slot` and folds it in if it is a candidate.  Triangles outside
-// [begin_id, end_id) and `current` are skipped.
+// Tests the triangle of leaf slot `slot` and folds it in if it is a candidate; `current` is skipped.  (A hierarchy
+// holds exactly the triangles it is searched for: all of them, or the emissive ones.)
 template <class WS>
-RT_DEV void closest_fold_leaf(const DBvh &bv, const WS &ws, const Ray &ray, int slot, int begin_id, int end_id, int current,
-                              ClosestFold &cf) {
+RT_DEV void closest_fold_leaf(const DBvh &bv, const WS &ws, const Ray &ray, int slot, int current, ClosestFold &cf) {
     const Tri t = load_leaf_tri(bv, ws, slot);
     const float det = -dot(ray.d, t.n);
     const f3 delta = ray.o - t.p;
@@ -380,7 +389,7 @@ RT_DEV void closest_fold_leaf(const DBvh &bv, const WS &ws, const Ray &ray, int 
     float rx, ry;
     if (!inside_test(ray, t, pt, rx, ry)) return;
     const int id = leaf_tri_id(bv, ws, slot);
-    if (id < begin_id || id >= end_id || id == current) return;
+    if (id == current) return;
     // a candidate: rule 3 between it and the running best
     bool take;
     if (cf.best < 0) take = true;
@@ -418,7 +427,7 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
     const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
     ClosestFold cf;
     closest_fold_reset(cf, w_init);
-    auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, begin_id, end_id, current, cf); return true; };
+    auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, current, cf); return true; };
     auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
     bvh_traverse(bv, br, active && br.finite, ws, leaf, limit, cnt);
     closest_fold_redo(sc, ray, active && (!br.finite || cf.n_near > 2), begin_id, end_id, current, w_init, cf);
@@ -453,7 +462,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
     int owner = lane;
     BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
     TravState ts;
-    ts.node = 0; ts.sp = 0; ts.run = active;
+    trav_begin(ws, ts, active);
     auto leaf = [&](int slot) -> bool {
         if (test(ray, extra, slot)) { flags[owner] = 1; return false; }
         return true;
@@ -463,14 +472,14 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
         if (ts.run && flags[owner] != 0) ts.run = false;          // another helper of this query has found a hit
         const unsigned long long running = __builtin_amdgcn_ballot_w64(ts.run);
         if (running == 0ull) break;
-        const unsigned long long donors = __builtin_amdgcn_ballot_w64(ts.run && ts.sp > 0);
+        const unsigned long long donors = __builtin_amdgcn_ballot_w64(ts.run && ts.sp > 1);
         const int n_idle = 64 - (int)__popcll(running), n_donors = (int)__popcll(donors);
         if (n_idle >= SHARE_MIN_IDLE && n_donors > 0) {
             const int n_take = n_idle < n_donors ? n_idle : n_donors;
             const unsigned long long idle = ~running;
             const int d_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
             const int i_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const bool gives = ts.run && ts.sp > 0 && d_rank < n_take;
+            const bool gives = ts.run && ts.sp > 1 && d_rank < n_take;
             const bool takes = !ts.run && i_rank < n_take;
             if (gives) table[d_rank] = (unsigned char)lane;
             // the entry a donor hands over: the top of its stack
@@ -492,7 +501,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
                 ray = r2; br.inv = b2.inv; br.ca = b2.ca; br.cb = b2.cb; extra = e2; lim = l2;
                 if (WS::RES) bvh_ray_offsets(br);
                 owner = t_owner;
-                ts.node = t_node; ts.sp = 0; ts.run = true;
+                ts.node = t_node; ts.sp = 1; ts.run = true;
             }
         }
         bvh_advance<(NODE_BUDGET > 0)>(bv, br, ws, ts, SHARE_MIN_IDLE, leaf, limit, cnt, true, NODE_BUDGET > 0 ? NODE_BUDGET : 1 << 30);

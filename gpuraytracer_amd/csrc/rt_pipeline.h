@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     size_t i = region;
     bool busy = false;
     TravState ts;
-    ts.node = 0; ts.sp = 0; ts.run = false;
+    trav_begin(ws, ts, false);
     Ray ray;
     ray.o = ray.d = mk3(0.0f, 0.0f, 0.0f);
     BvhRay br = bvh_ray_setup<CFG::RES>(ray, bv.max_abs_coord);
@@ -1073,10 +1073,10 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
             br = bvh_ray_setup<CFG::RES>(ray, bv.max_abs_coord);
             closest_fold_reset(cf, 1.0f);
             busy = true;
-            ts.node = 0; ts.sp = 0; ts.run = br.finite;
+            ts.node = 0; ts.sp = 1; ts.run = br.finite;
         }
         if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
-        auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, 0, sc.count, -1, cf); return true; };
+        auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, -1, cf); return true; };
         auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
         bvh_advance(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
         const bool fin = busy && !ts.run;
