@@ -292,6 +292,9 @@ struct PipeBuffers {
                                                 // then [MAX_ROUNDS + 1] `more` flags: more[r] != 0 = round r of the pass left chunks undone
     uint32_t *resume;                           // [PIPE_WAVES] the fixed share of each wave: how far the rounds so far have come;
                                                 // then one word that is set if the last round of a pass ever left chunks undone
+    uint32_t *claim;                            // [PIPE_WAVES] pool blocks of each region of the extend queue handed out so far (k_extend);
+                                                // zero between the launches that use it
+    unsigned long long *pool_map;               // [PIPE_WAVES / 64] one bit per region whose pool may have blocks left (k_extend)
     uint32_t region_cap;
     uint32_t round, rounds;                     // round of the pass these launches belong to, and how many it has (see MAX_ROUNDS)
     unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
@@ -502,13 +505,39 @@ RT_DEV bool first_path(const DFrame &fr, uint32_t sample, uint32_t in_sample, ui
 
 // Extend stage of the bounces after the first: closest hit of every path of the wave's queue region, then the
 // shading up to the probe loop (shade_and_route).
+//
+// Regions hold about the same number of records, but the records differ in cost, and with every wave bound to its own
+// region a tenth (424 triangles) to a quarter (_ObiWan) of the wave slots stood empty while the slowest waves finished.
+// So the last quarter of every region's 64-record blocks is a pool: its blocks are handed out through a counter per
+// region (b.claim), to the region's own wave when it gets there and to any wave that has run out of work before
+// (it looks through the regions after its own, 64 at a time).  Survivors go to the regions of the wave that processed
+// them, which takes foreign blocks only while its regions have room for all of their paths; a path's arithmetic does
+// not depend on where it is processed, so the image stays the same bits.
+#ifndef RT_POOL_SHARE
+#define RT_POOL_SHARE 4
+#endif
+constexpr uint32_t POOL_SHARE = RT_POOL_SHARE;       // 1/POOL_SHARE of a region's blocks can be taken by other waves; 0: none
+#ifndef RT_STEAL_TRIES
+#define RT_STEAL_TRIES 1
+#endif
+constexpr uint32_t STEAL_TRIES = RT_STEAL_TRIES;     // a wave gives up looking for foreign blocks after so many claims that came too late
+RT_DEV uint32_t pool_first_block(uint32_t n_blocks) { return POOL_SHARE ? n_blocks - n_blocks / POOL_SHARE : n_blocks; }
+#ifndef RT_STEAL_BLOCKS
+#define RT_STEAL_BLOCKS 4
+#endif
+constexpr uint32_t STEAL_BLOCKS = RT_STEAL_BLOCKS;   // blocks a wave takes from another region's pool with one claim
+RT_DEV uint32_t claim_block(const PipeBuffers &b, uint32_t region, uint32_t n = 1u) {
+    uint32_t c = 0;
+    if (lane_index() == 0) c = atomicAdd(&b.claim[region], n);
+    return c;       // valid in lane 0
+}
+
 template <class CFG>
 __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_extend(DScene sc, DBvh bv, DFrame fr, PipeBuffers b, int depth, int q_in,
                                                           PassTables tab, uint32_t paths_per_sample, int max_depth) {
     if (round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
     const uint32_t total = b.n_ext[q_in][wave];
-    const size_t region = (size_t)wave * b.region_cap;
     RT_TRAVERSAL_LDS(CFG);
     typename CFG::WS ws, lws;
     lds_u8_ptr share;
@@ -519,12 +548,74 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
 
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t qi = base + lane;
-        const bool live = qi < total;
+    const uint32_t n_blocks = (total + 63u) >> 6, pool0 = pool_first_block(n_blocks);
+    const uint32_t *counts = b.n_ext[q_in];
+    // where the next block comes from: 0 the wave's own blocks before the pool, 1 the pool of its own region (the next
+    // claim is under way while a block is processed), 2 the pools of the other regions
+    int phase = 0;
+    uint32_t next_own = 0, ahead = 0, failed = 0, pick = wave * 2654435761u;
+    uint32_t got_src = 0, got_total = 0, got_next = 0, got_end = 0;      // blocks of another region this wave has claimed
+    if (POOL_SHARE && n_blocks > pool0 && lane == 0) atomicOr(&b.pool_map[wave >> 6], 1ull << (wave & 63u));
+    for (;;) {
+        uint32_t src = wave, src_total = total, block = 0;      // block `block` of region `src`, which holds `src_total` records
+        if (phase == 0) {
+            if (next_own < pool0) {
+                block = next_own++;
+            } else {
+                if (!POOL_SHARE) break;
+                phase = 1;
+                ahead = claim_block(b, wave);
+                continue;
+            }
+        } else if (phase == 1) {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
+            if (pool0 + c >= n_blocks) {
+                // the region's pool is used up (every wave that finds it so says so; the owner always gets here, so the
+                // map is all zeros again when the kernel ends)
+                if (lane == 0 && n_blocks > pool0) atomicAnd(&b.pool_map[wave >> 6], ~(1ull << (wave & 63u)));
+                phase = 2;
+                continue;
+            }
+            ahead = claim_block(b, wave);
+            block = pool0 + c;
+        } else if (got_next < got_end) {
+            src = got_src; src_total = got_total; block = got_next++;
+        } else {
+            // only while this wave's regions can take all the paths of the blocks of another claim (what goes to the probe
+            // regions may come on to the next extend region), and not for ever: near the end many waves look for the same few blocks
+            if (failed >= STEAL_TRIES || fill.next + fill.shadow + fill.glossy + 64u * STEAL_BLOCKS > b.region_cap) break;
+            // b.pool_map: one bit per region whose pool may have blocks left (lane l reads the word of regions 64 l ...).  The
+            // words change under way: read past this XCD's L2, which may hold an old value for as long as it likes.
+            const unsigned long long word = __hip_atomic_load(&b.pool_map[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long lanes = __builtin_amdgcn_ballot_w64(word != 0ull);
+            if (lanes == 0ull) break;
+            // a set bit picked by a number that differs from wave to wave and from try to try, so that the idle waves spread
+            // over the regions that have work left
+            pick = pick * 1664525u + 1013904223u;
+            const uint32_t r1 = (pick >> 8) & 63u, r2 = (pick >> 16) & 63u;
+            const unsigned long long lanes_rot = (lanes >> r1) | (r1 ? lanes << (64u - r1) : 0ull);
+            const uint32_t l = ((uint32_t)__builtin_ctzll(lanes_rot) + r1) & 63u;
+            const unsigned long long w = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)word, (int)l) |
+                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(word >> 32), (int)l) << 32);
+            const unsigned long long w_rot = (w >> r2) | (r2 ? w << (64u - r2) : 0ull);
+            src = l * 64u + (((uint32_t)__builtin_ctzll(w_rot) + r2) & 63u);
+            src_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)counts[src]);
+            const uint32_t nb = (src_total + 63u) >> 6;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_block(b, src, STEAL_BLOCKS));
+            if (pool_first_block(nb) + c >= nb) {       // used up: another wave was faster
+                if (lane == 0) atomicAnd(&b.pool_map[src >> 6], ~(1ull << (src & 63u)));
+                failed++;
+                continue;
+            }
+            block = pool_first_block(nb) + c;
+            got_src = src; got_total = src_total; got_next = block + 1u;
+            got_end = block + STEAL_BLOCKS < nb ? block + STEAL_BLOCKS : nb;
+        }
+        const uint32_t qi = block * 64u + lane;
+        const bool live = qi < src_total;
         uint32_t id = 0, kept_flags = 0;
         PathState ps;
-        load_path_rec(b, q_in, region + (live ? qi : 0u), ps, id, kept_flags);
+        load_path_rec(b, q_in, (size_t)src * b.region_cap + (live ? qi : 0u), ps, id, kept_flags);
         n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
@@ -1002,7 +1093,10 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
         if (live) go_on = retire_glossy(sc, fr, b, i, h, outcome, light_id, lsec, deeper, ps, kept_flags);
         route_next(b, q_in ^ 1, fill_next, live, go_on, ps, h.id, kept_flags);
     }
-    if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
+    if (lane == 0) {
+        b.n_ext[q_in ^ 1][wave] = fill_next;
+        b.claim[wave] = 0;          // used by the extend stage before this one, and by the next
+    }
     wstat_add(b, WSTAT_GLOSSY, total);
     if (CFG::BVH) {
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
@@ -1137,7 +1231,7 @@ struct Pipeline {
     }
     std::vector<void **> counter_buffers() {
         return {(void **)&buf.wstats, (void **)&buf.n_ext[0], (void **)&buf.n_ext[1], (void **)&buf.n_shadow, (void **)&buf.n_glossy,
-                (void **)&buf.work, (void **)&buf.resume};
+                (void **)&buf.work, (void **)&buf.resume, (void **)&buf.claim, (void **)&buf.pool_map};
     }
 
     void free_paths() {
@@ -1185,6 +1279,14 @@ struct Pipeline {
             PIPE_ALLOC(buf.n_glossy, sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.work, sizeof(uint32_t) * (N_RUNS + MAX_ROUNDS + 1));
             PIPE_ALLOC(buf.resume, sizeof(uint32_t) * (PIPE_WAVES + 1));
+            PIPE_ALLOC(buf.claim, sizeof(uint32_t) * PIPE_WAVES);
+            *what = "memset claim";
+            e = hipMemset(buf.claim, 0, sizeof(uint32_t) * PIPE_WAVES);
+            if (e != hipSuccess) goto failed;
+            PIPE_ALLOC(buf.pool_map, sizeof(unsigned long long) * (PIPE_WAVES / 64));
+            *what = "memset pool_map";
+            e = hipMemset(buf.pool_map, 0, sizeof(unsigned long long) * (PIPE_WAVES / 64));
+            if (e != hipSuccess) goto failed;
             *what = "memset resume";
             e = hipMemset(buf.resume, 0, sizeof(uint32_t) * (PIPE_WAVES + 1));
             if (e != hipSuccess) goto failed;
