@@ -6,9 +6,9 @@
 Workload (the configuration the headline metric is quoted on): the reference's bundled `cubes` scene (424 triangles, 24 of
 them emissive), 1920x1080, RECURSION 6, CLOCK 95834783, default camera, constant environment
 (the reference's .exr environment is not in its repository; data is synthetic in that sense).
-One step renders `--spp-per-step` samples per pixel in one pass (256 by default, the largest pass the library takes:
-66 GB of path queues at 1080p); the default 4 steps are the 1024 spp of the metric, so `seconds_to_1024spp` is the timed
-region itself.  Rays = findIntersection
+One step renders `--spp-per-step` samples per pixel in one pass (512 by default, the largest pass the library takes:
+132 GB of path queues at 1080p; passes of 256 samples, 66 GB, are 2.5 % slower); the default 2 steps are the 1024 spp of
+the metric, so `seconds_to_1024spp` is the timed region itself.  Rays = findIntersection
 executions (one per bounce entered); light probes are counted separately.
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU) the scene is replicated and rank r renders
@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-SPP_PER_STEP = 256          # samples per step and pass by default; the counter files under profiles/ are measured with it
+SPP_PER_STEP = 512          # samples per step and pass by default; the counter files under profiles/ are measured with it
 # Vector-instruction issue of gfx950 as measured by tools/microbench_valu.hip (profiles/r02_valu_ceiling.txt): a SIMD
 # sustains one wave64 instruction per 2.32 clocks for v_fma/v_mul/v_add/v_mov/integer add/logic (and for mixes of those
 # with the slower kinds), one per 4.2 clocks for v_min/v_max/v_cmp/v_cndmask/shifts/conversions/packed f32.
@@ -152,7 +152,7 @@ def profile_counters(workload, kernel_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
     ap.add_argument("--total-spp", type=int, default=0,

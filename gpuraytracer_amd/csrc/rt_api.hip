@@ -635,10 +635,10 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
         const uint32_t n = (sample_count - done < chunk_max) ? sample_count - done : chunk_max;
         PassTables tab;
         tab.n = n;
-        for (uint32_t k = 0; k < (uint32_t)MAX_BATCH; k++) {
-            tab.sample[k] = k < n ? sample_begin + (done + k) * sample_stride : 0u;
-            tab.light_seed[k] = k < n ? light_seed_for(ctx, tab.sample[k]) : 0u;
-        }
+        tab.first_sample = sample_begin + done * sample_stride;
+        tab.stride = sample_stride;
+        for (uint32_t k = 0; k < (uint32_t)MAX_BATCH; k++)
+            tab.light_seed[k] = k < n ? light_seed_for(ctx, tab.first_sample + k * sample_stride) : 0u;
         if (ctx->pipeline == 0) {
             if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
             const uint32_t tiles = ((ctx->width + 7u) >> 3) * ((ctx->height + 7u) >> 3);

@@ -16,19 +16,19 @@ struct DStats {
     unsigned long long ext_nodes, ext_tris, probe_nodes, probe_tris;
 };
 
-// The per-pass tables travel by value in the kernel arguments (1 KB), so a pass needs no host-to-device copy and no
-// staging buffer: SAMPLE of every slot of the batch, and its light_seed = CLOCK hashed SAMPLE times
-// (raytracer.glsl:595-598).  The coin of a bounce (raytracer.glsl:553: unitFloat(light_seed) < 0.5, drawn once per
-// bounce from a stream all pixels of a sample share) is recomputed from light_seed where it is needed.
+// The per-pass table travels by value in the kernel arguments (2 KB), so a pass needs no host-to-device copy and no
+// staging buffer: the SAMPLE of slot k of the batch is first_sample + k * stride, and light_seed[k] is its light seed =
+// CLOCK hashed SAMPLE times (raytracer.glsl:595-598).  The coin of a bounce (raytracer.glsl:553: unitFloat(light_seed)
+// < 0.5, drawn once per bounce from a stream all pixels of a sample share) is recomputed from light_seed where it is needed.
 #ifndef RT_MAX_BATCH
-#define RT_MAX_BATCH 256
+#define RT_MAX_BATCH 512
 #endif
 constexpr int MAX_BATCH = RT_MAX_BATCH;
 struct PassTables {
-    uint32_t n;
-    uint32_t sample[MAX_BATCH];
+    uint32_t n, first_sample, stride;
     uint32_t light_seed[MAX_BATCH];
 };
+RT_DEV uint32_t sample_of_slot(const PassTables &tab, uint32_t k) { return tab.first_sample + k * tab.stride; }
 // light_seed after the draws of `depth` earlier bounces
 RT_DEV uint32_t light_seed_at(uint32_t light_seed, int depth) {
     for (int d = 0; d < depth; d++) light_seed = pcg_hash(light_seed);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
 
     for (uint32_t k = 0; k < tab.n; k++) {
-        const uint32_t sample = tab.sample[k];
+        const uint32_t sample = sample_of_slot(tab, k);
         uint32_t light_seed = tab.light_seed[k];
         PathState ps;
         ps.seed = pixel_seed(fr, tx, ty, sample);

@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         const uint32_t base = slot * paths_per_sample + tile_of_chunk * 64u;
         const uint32_t id = base + lane;
         PathState ps;
-        const bool live = first_path(fr, tab.sample[slot], base - slot * paths_per_sample, tiles_x, id < total, ps);
+        const bool live = first_path(fr, sample_of_slot(tab, slot), base - slot * paths_per_sample, tiles_x, id < total, ps);
         n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;

@@ -193,7 +193,7 @@ int rt_reset_stats(rt_context *ctx);
 /* Tuning knobs; unknown names return RT_ERR_INVALID.  None of them changes a result.
  *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
  *                   1 = staged kernels over compacted ray queues (default)
- *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 256; the queues of a pass
+ *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 512; the queues of a pass
  *                   take about 44 + 240 / queue_rounds bytes of device memory per pixel and sample,
  *                   rt_stats.queue_bytes tells)
  *   "queue_rounds"  n in [1, 8] (default 3): the path queues hold 1/n of the paths a pass would hand on if every path

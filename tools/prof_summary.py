@@ -14,7 +14,7 @@ try:
     command = open(os.path.join(base, "command.txt")).read().strip()
 except OSError:
     command = "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bruteforce-pass"
-out = ["# rocprofv3 summary '%s': %s\n# (3 passes of 256 spp each at 1920x1080 unless the command says otherwise: 3 launches of "
+out = ["# rocprofv3 summary '%s': %s\n# (3 passes of 512 spp each at 1920x1080 unless the command says otherwise: 3 launches of "
        "the depth-0 kernel)\n" % (tag, command)]
 def newest(pattern):
     """gpurun merges every run's files into the same directories: take the latest."""
