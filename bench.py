@@ -7,8 +7,8 @@ Workload (the configuration the headline metric is quoted on): the reference's b
 them emissive), 1920x1080, RECURSION 6, CLOCK 95834783, default camera, constant environment
 (the reference's .exr environment is not in its repository; data is synthetic in that sense).
 One step renders `--spp-per-step` samples per pixel in one pass (512 by default, the largest pass the library takes:
-132 GB of path queues at 1080p; passes of 256 samples, 66 GB, are 2.5 % slower); the default 2 steps are the 1024 spp of
-the metric, so `seconds_to_1024spp` is the timed region itself.  Rays = findIntersection
+132 GB of path queues at 1080p; passes of 256 samples, 66 GB, are 2.5 % slower); the default 4 steps are 2048 spp, and
+`seconds_per_1024spp` is the timed region scaled to the 1024 spp of the metric.  Rays = findIntersection
 executions (one per bounce entered); light probes are counted separately.
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU) the scene is replicated and rank r renders
@@ -152,7 +152,7 @@ def profile_counters(workload, kernel_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
     ap.add_argument("--total-spp", type=int, default=0,
@@ -305,10 +305,10 @@ def main():
         ext_ms, ext_n = st["extend0_ms"], max(1, st["extend0_launches"])
         used_bvh = st["bvh_extend_nodes"] > 0
         if used_bvh:
-            # Nodes and triangles come from LDS/L1/L2; what has to cross HBM is what the stage leaves behind: a 16-byte
+            # Nodes and triangles come from LDS/L1/L2; what has to cross HBM is what the stage leaves behind: a 12-byte
             # radiance record per path that ended, a 64-byte path record per path that goes on.
             d1 = float(st["depth1_paths"])
-            algo = (float(st["pixel_samples"]) - d1) * 16.0 + d1 * 64.0
+            algo = (float(st["pixel_samples"]) - d1) * 12.0 + d1 * 64.0
             achieved = algo / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
             prof, provenance = profile_counters(args.workload, "k_first<")
             comparable = prof is not None and args.spp_per_step == SPP_PER_STEP and (W, H) == (1920, 1080)
@@ -370,6 +370,7 @@ def main():
                        "closest_hit": "hierarchy (exact)" if used_bvh else "loop over all triangles",
                        "parallelism": ("spp split x%d, sums gathered over RCCL and added in rank order" % world) if world > 1 else "1 GPU"},
             "seconds_to_%dspp" % (args.total_spp if strong else steps * spp): dt,
+            "seconds_per_1024spp": dt * 1024.0 / float(args.total_spp if strong else steps * spp),
             "reduce_ms": reduce_ms if dist is not None else 0.0,
             "probe_rays_per_s_M": probes / dt / 1e6,
             "rays_per_pixel_sample": rays / max(1.0, float(st["pixel_samples"]) * world),
