@@ -71,7 +71,10 @@ def main():
         want, wst = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=3, batch=batches[0], cam=cam)
         line = "seed %d: %d tris %dx%d spp %d rec %d rays %d" % (seed, len(scene[0]), w, h, spp, rec, wst["rays"])
         for k, form in enumerate((1, 5, 7, 6)):
-            img, st = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=form, batch=batches[k % 3 + 1], cam=cam)
+            # queues for the whole pass, or for a fraction of it (passes that do not fit take further rounds)
+            rounds = (1, 3, 8, 2)[(seed + k) % 4]
+            img, st = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=form, batch=batches[k % 3 + 1], cam=cam,
+                                rounds=rounds)
             same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
             ok = same.all() and all(st[key] == wst[key] for key in ("rays", "shadow_probes", "glossy_probes"))
             if not ok:
