@@ -172,8 +172,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--unordered-reduce", action="store_true", help="N > 1: one RCCL reduce(SUM) instead of gather + add in rank order")
     ap.add_argument("--lane-utilisation", type=int, default=-1,
-                    help="add the lane utilisation of the traversal loops (two extra 32 spp renders in child processes); "
-                         "-1: only for --workload obiwan")
+                    help="0: leave out the traversal work per query and the lane utilisation of the traversal loops (two extra "
+                         "32 spp renders with the measurement builds of the library, in child processes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
@@ -303,7 +303,8 @@ def main():
         # dominant kernel: the depth-0 launches (camera ray, closest hit, shading, probe in place, rest of the bounce);
         # their time comes from HIP events on the context's stream (rt_stats), recorded inside the timed region
         ext_ms, ext_n = st["extend0_ms"], max(1, st["extend0_launches"])
-        used_bvh = st["bvh_extend_nodes"] > 0
+        # the library's own rule (gpurt.h, option "accel"): hierarchy from 64 triangles on unless it is turned off
+        used_bvh = args.accel != 0 and len(scene[0]) >= 64
         if used_bvh:
             # Nodes and triangles come from LDS/L1/L2; what has to cross HBM is what the stage leaves behind: a 12-byte
             # radiance record per path that ended, a 64-byte path record per path that goes on.
@@ -376,7 +377,6 @@ def main():
             "rays_per_pixel_sample": rays / max(1.0, float(st["pixel_samples"]) * world),
             "mean_radiance": mean,
             "nonfinite_pixels": nonfinite_pixels,
-            "bvh": {k: st[k] for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris")},
             "queue_memory_bytes": int(st["queue_bytes"]),
             "scene_upload_s": upload_s,
             "roofline": roof,
@@ -408,7 +408,9 @@ def main():
                 "flops_per_launch": f1 / max(1, s1["extend0_launches"]),
                 "value_Mrays_per_s": s1["rays"] / dt1 / 1e6, "sample": "64 spp, RECURSION 1",
                 "note": "flops counted as full tests; triangles whose plane test fails for the whole wave skip the rest"}
-        want_lanes = args.lane_utilisation == 1 or (args.lane_utilisation < 0 and args.workload == "obiwan")
+        # node visits and triangle tests per query and the lane utilisation of the traversal loops: two 32 spp renders with
+        # the measurement builds of the library in child processes (the product does not count its traversal steps)
+        want_lanes = args.lane_utilisation != 0
         if want_lanes and world == 1 and args.workload in ("cubes", "obiwan"):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import lane_utilisation

@@ -205,16 +205,20 @@ RT_DEV void box_slabs(const BvhRay &br, f3 lo, f3 hi, float t_max, float &t_in, 
 }
 
 struct BvhCounters { uint32_t nodes, tris; };
-// Normal builds count the node visits and triangle tests of every lane.  With -DRT_COUNT_WAVE_STEPS the first
-// active lane adds 64 per step instead, i.e. the lane slots the wave spent: the ratio of the two builds'
-// numbers is the lane utilisation of the traversal loops.
-#ifdef RT_COUNT_WAVE_STEPS
+// Counting the node visits and triangle tests costs the traversal loops one vector instruction per step and the
+// kernels four registers (1.4 % of the headline rate), so the product does not: the counters stay zero.  Two
+// measurement builds do.  -DRT_COUNT_STEPS (libgpurt_steps.so): every lane counts its own steps.
+// -DRT_COUNT_WAVE_STEPS (libgpurt_wavesteps.so): the first active lane adds 64 per step instead, i.e. the lane slots
+// the wave spent; the ratio of the two builds' numbers is the lane utilisation of the traversal loops.
+#if defined(RT_COUNT_WAVE_STEPS)
 RT_DEV uint32_t bvh_count_step() {
     const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u)) == 0u ? 64u : 0u;
 }
-#else
+#elif defined(RT_COUNT_STEPS)
 RT_DEV uint32_t bvh_count_step() { return 1u; }
+#else
+RT_DEV uint32_t bvh_count_step() { return 0u; }
 #endif
 
 // Traversal state of one lane; it survives between calls of bvh_advance, so that a wave can hand finished

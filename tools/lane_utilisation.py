@@ -1,6 +1,7 @@
-"""Lane utilisation of the traversal loops: renders the same frames with the product library and with the variant
-built with -DRT_COUNT_WAVE_STEPS (gpuraytracer_amd/libgpurt_wavesteps.so; its traversal counters count the lane
-slots a wave spends), each in a child process, and divides the counters.
+"""Lane utilisation of the traversal loops: renders the same frames with the two measurement builds of the library,
+-DRT_COUNT_STEPS (gpuraytracer_amd/libgpurt_steps.so: every lane counts its node visits and triangle tests) and
+-DRT_COUNT_WAVE_STEPS (libgpurt_wavesteps.so: the lane slots a wave spends on them), each in a child process, and
+divides the counters.
 Usage: python tools/lane_utilisation.py [cubes|obiwan] [recursion]"""
 import json
 import os
@@ -8,6 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS = os.path.join(ROOT, "gpuraytracer_amd", "libgpurt_steps.so")
 VARIANT = os.path.join(ROOT, "gpuraytracer_amd", "libgpurt_wavesteps.so")
 CHILD = r'''
 import os, sys, json
@@ -35,7 +37,7 @@ def _run(lib, name, rec):
 
 def measure(name, recursion):
     """{counter: (steps per query, lane slots per query, utilisation)} for 32 spp at 1080p."""
-    a = _run(None, name, recursion)
+    a = _run(os.environ.get("GPURT_LIB_STEPS", STEPS), name, recursion)
     b = _run(os.environ.get("GPURT_LIB_WAVE_STEPS", VARIANT), name, recursion)
     res = {"rays": a["rays"], "probes": a["shadow_probes"] + a["glossy_probes"]}
     for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris"):
