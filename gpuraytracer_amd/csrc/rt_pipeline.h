@@ -292,11 +292,12 @@ struct PipeBuffers {
                                                 // then [MAX_ROUNDS + 1] `more` flags: more[r] != 0 = round r of the pass left chunks undone
     uint32_t *resume;                           // [PIPE_WAVES] the fixed share of each wave: how far the rounds so far have come;
                                                 // then one word that is set if the last round of a pass ever left chunks undone
-    uint32_t *claim;                            // [PIPE_WAVES] pool blocks of each region of the extend queue handed out so far (k_extend);
-                                                // zero between the launches that use it
+    uint32_t *claim;                            // [3][PIPE_WAVES] pool blocks of each region handed out so far, for the extend, the shadow
+                                                // and the glossy stage; each zero when its stage starts
     unsigned long long *pool_map;               // [PIPE_WAVES / 64] one bit per region whose pool may have blocks left (k_extend)
     uint32_t region_cap;
     uint32_t round, rounds;                     // round of the pass these launches belong to, and how many it has (see MAX_ROUNDS)
+    uint32_t defer_below;                       // depth-0 chunks with fewer probes than this leave them to the probe stages; 0: never
     unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
 };
 
@@ -431,6 +432,22 @@ RT_DEV void wstat_add(const PipeBuffers &b, int which, unsigned long long v) {
 
 struct RouteFill { uint32_t shadow, glossy, next; };
 
+// A probe record (see the head of this file) at position i of the probe queue.
+RT_DEV void store_probe_rec(const PipeBuffers &b, size_t i, const PathState &ps, uint32_t id, int hit, uint32_t kept_flags,
+                            const Bounce &bn, bool shadow) {
+    b.pa[i] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+    b.pb[i] = make_float4(ps.d.y, ps.d.z, ps.path.x, ps.path.y);
+    b.pc[i] = make_float4(ps.path.z, ps.energy.x, ps.energy.y, ps.energy.z);
+    b.pd[i] = make_uint4(ps.seed, id, (uint32_t)hit | (kept_flags << 30), 0u);
+    b.p0[i] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
+    if (shadow) {
+        b.p1[i] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, bn.roughness);
+        b.p2[i] = make_float4(bn.albedo.x, bn.albedo.y, bn.albedo.z, 0.0f);
+    } else {
+        b.p1[i] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
+    }
+}
+
 // Shading of one path after its closest hit is known (raytracer.glsl:452-556): adds the sky on a
 // miss, otherwise runs shade_pre and hands the path to the shadow queue, the glossy queue or (no
 // probe needed) through the rest of the bounce to the next extend queue.  Called by whole waves.
@@ -461,20 +478,8 @@ RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffer
     const size_t base = (size_t)wave_index() * b.region_cap;
     const uint32_t s_slot = region_slot(fill.shadow, to_shadow);
     const uint32_t g_slot = region_slot(fill.glossy, to_glossy);
-    if (to_shadow | to_glossy) {
-        const size_t i = to_shadow ? base + s_slot : base + (b.region_cap - 1u - g_slot);
-        b.pa[i] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-        b.pb[i] = make_float4(ps.d.y, ps.d.z, ps.path.x, ps.path.y);
-        b.pc[i] = make_float4(ps.path.z, ps.energy.x, ps.energy.y, ps.energy.z);
-        b.pd[i] = make_uint4(ps.seed, id, (uint32_t)hit | (kept_flags << 30), 0u);
-        b.p0[i] = make_float4(bn.probe_d.x, bn.probe_d.y, bn.probe_d.z, bn.max_t);
-        if (to_shadow) {
-            b.p1[i] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, bn.roughness);
-            b.p2[i] = make_float4(bn.albedo.x, bn.albedo.y, bn.albedo.z, 0.0f);
-        } else {
-            b.p1[i] = make_float4(bn.c.x, bn.c.y, bn.c.z, bn.w);
-        }
-    }
+    if (to_shadow | to_glossy)
+        store_probe_rec(b, to_shadow ? base + s_slot : base + (b.region_cap - 1u - g_slot), ps, id, hit, kept_flags, bn, to_shadow);
     route_next(b, q_in ^ 1, fill.next, live && !(to_shadow | to_glossy), go_on, ps, id, kept_flags);
 }
 
@@ -517,19 +522,104 @@ RT_DEV bool first_path(const DFrame &fr, uint32_t sample, uint32_t in_sample, ui
 #define RT_POOL_SHARE 4
 #endif
 constexpr uint32_t POOL_SHARE = RT_POOL_SHARE;       // 1/POOL_SHARE of a region's blocks can be taken by other waves; 0: none
+#ifndef RT_PROBE_POOL_SHARE
+#define RT_PROBE_POOL_SHARE 2
+#endif
+constexpr uint32_t PROBE_POOL_SHARE = RT_PROBE_POOL_SHARE;      // the same for the probe stages
 #ifndef RT_STEAL_TRIES
 #define RT_STEAL_TRIES 1
 #endif
 constexpr uint32_t STEAL_TRIES = RT_STEAL_TRIES;     // a wave gives up looking for foreign blocks after so many claims that came too late
-RT_DEV uint32_t pool_first_block(uint32_t n_blocks) { return POOL_SHARE ? n_blocks - n_blocks / POOL_SHARE : n_blocks; }
 #ifndef RT_STEAL_BLOCKS
 #define RT_STEAL_BLOCKS 4
 #endif
 constexpr uint32_t STEAL_BLOCKS = RT_STEAL_BLOCKS;   // blocks a wave takes from another region's pool with one claim
-RT_DEV uint32_t claim_block(const PipeBuffers &b, uint32_t region, uint32_t n = 1u) {
+RT_DEV uint32_t claim_block(uint32_t *claim, uint32_t region, uint32_t n = 1u) {
     uint32_t c = 0;
-    if (lane_index() == 0) c = atomicAdd(&b.claim[region], n);
+    if (lane_index() == 0) c = atomicAdd(&claim[region], n);
     return c;       // valid in lane 0
+}
+// Hands a wave the 64-record blocks it is to process, one per call of feed_next: its own blocks before the pool, then
+// the pool of its own region (the next claim is under way while a block is processed), then blocks from the pools of
+// other regions.  `counts` = records per region, `claim` = the stage's counters (zero at the start of the kernel),
+// `share`: 1/share of a region's blocks are its pool (1: all of them).  All values are wave-uniform.
+struct BlockFeed {
+    const uint32_t *counts;
+    uint32_t *claim;
+    uint32_t share, total, n_blocks, pool0;
+    int phase;
+    uint32_t next_own, ahead, failed, pick;
+    uint32_t got_src, got_total, got_next, got_end;      // blocks of another region this wave has claimed
+};
+RT_DEV uint32_t feed_pool_first(uint32_t n_blocks, uint32_t share) { return share ? n_blocks - n_blocks / share : n_blocks; }
+RT_DEV void feed_begin(BlockFeed &f, const PipeBuffers &b, const uint32_t *counts, uint32_t *claim, uint32_t share) {
+    const uint32_t wave = wave_index();
+    f.counts = counts; f.claim = claim; f.share = share;
+    f.total = counts[wave];
+    f.n_blocks = (f.total + 63u) >> 6;
+    f.pool0 = feed_pool_first(f.n_blocks, share);
+    f.phase = 0;
+    f.next_own = 0; f.ahead = 0; f.failed = 0; f.pick = wave * 2654435761u;
+    f.got_src = f.got_total = f.got_next = f.got_end = 0;
+    if (share && f.n_blocks > f.pool0 && lane_index() == 0) atomicOr(&b.pool_map[wave >> 6], 1ull << (wave & 63u));
+}
+// The next block: block `block` of region `src`, which holds `src_total` records; false when there is none.
+// `room_for_foreign`: this wave's regions can take all the paths of the blocks of another claim (64 * STEAL_BLOCKS).
+RT_DEV bool feed_next(BlockFeed &f, const PipeBuffers &b, bool room_for_foreign, uint32_t &src, uint32_t &src_total, uint32_t &block) {
+    const uint32_t lane = lane_index(), wave = wave_index();
+    for (;;) {
+        src = wave; src_total = f.total;
+        if (f.phase == 0) {
+            if (f.next_own < f.pool0) { block = f.next_own++; return true; }
+            if (!f.share) return false;
+            f.phase = 1;
+            f.ahead = claim_block(f.claim, wave);
+        } else if (f.phase == 1) {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.ahead);
+            if (f.pool0 + c < f.n_blocks) {
+                f.ahead = claim_block(f.claim, wave);
+                block = f.pool0 + c;
+                return true;
+            }
+            // the region's pool is used up (every wave that finds it so says so; the owner always gets here, so the
+            // map is all zeros again when the kernel ends)
+            if (lane == 0 && f.n_blocks > f.pool0) atomicAnd(&b.pool_map[wave >> 6], ~(1ull << (wave & 63u)));
+            f.phase = 2;
+        } else if (f.got_next < f.got_end) {
+            src = f.got_src; src_total = f.got_total; block = f.got_next++;
+            return true;
+        } else {
+            // not for ever: near the end many waves look for the same few blocks
+            if (f.failed >= STEAL_TRIES || !room_for_foreign) return false;
+            // b.pool_map: one bit per region whose pool may have blocks left (lane l reads the word of regions 64 l ...).  The
+            // words change under way: read past this XCD's L2, which may hold an old value for as long as it likes.
+            const unsigned long long word = __hip_atomic_load(&b.pool_map[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long lanes = __builtin_amdgcn_ballot_w64(word != 0ull);
+            if (lanes == 0ull) return false;
+            // a set bit picked by a number that differs from wave to wave and from try to try, so that the idle waves spread
+            // over the regions that have work left
+            f.pick = f.pick * 1664525u + 1013904223u;
+            const uint32_t r1 = (f.pick >> 8) & 63u, r2 = (f.pick >> 16) & 63u;
+            const unsigned long long lanes_rot = (lanes >> r1) | (r1 ? lanes << (64u - r1) : 0ull);
+            const uint32_t l = ((uint32_t)__builtin_ctzll(lanes_rot) + r1) & 63u;
+            const unsigned long long w = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)word, (int)l) |
+                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(word >> 32), (int)l) << 32);
+            const unsigned long long w_rot = (w >> r2) | (r2 ? w << (64u - r2) : 0ull);
+            const uint32_t victim = l * 64u + (((uint32_t)__builtin_ctzll(w_rot) + r2) & 63u);
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)f.counts[victim]);
+            const uint32_t nb = (t + 63u) >> 6, p0 = feed_pool_first(nb, f.share);
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_block(f.claim, victim, STEAL_BLOCKS));
+            if (p0 + c >= nb) {       // used up: another wave was faster
+                if (lane == 0) atomicAnd(&b.pool_map[victim >> 6], ~(1ull << (victim & 63u)));
+                f.failed++;
+                continue;
+            }
+            src = victim; src_total = t; block = p0 + c;
+            f.got_src = victim; f.got_total = t; f.got_next = block + 1u;
+            f.got_end = block + STEAL_BLOCKS < nb ? block + STEAL_BLOCKS : nb;
+            return true;
+        }
+    }
 }
 
 template <class CFG>
@@ -537,7 +627,6 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
                                                           PassTables tab, uint32_t paths_per_sample, int max_depth) {
     if (round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
-    const uint32_t total = b.n_ext[q_in][wave];
     RT_TRAVERSAL_LDS(CFG);
     typename CFG::WS ws, lws;
     lds_u8_ptr share;
@@ -548,69 +637,13 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
 
-    const uint32_t n_blocks = (total + 63u) >> 6, pool0 = pool_first_block(n_blocks);
-    const uint32_t *counts = b.n_ext[q_in];
-    // where the next block comes from: 0 the wave's own blocks before the pool, 1 the pool of its own region (the next
-    // claim is under way while a block is processed), 2 the pools of the other regions
-    int phase = 0;
-    uint32_t next_own = 0, ahead = 0, failed = 0, pick = wave * 2654435761u;
-    uint32_t got_src = 0, got_total = 0, got_next = 0, got_end = 0;      // blocks of another region this wave has claimed
-    if (POOL_SHARE && n_blocks > pool0 && lane == 0) atomicOr(&b.pool_map[wave >> 6], 1ull << (wave & 63u));
+    BlockFeed feed;
+    feed_begin(feed, b, b.n_ext[q_in], b.claim, POOL_SHARE);
     for (;;) {
-        uint32_t src = wave, src_total = total, block = 0;      // block `block` of region `src`, which holds `src_total` records
-        if (phase == 0) {
-            if (next_own < pool0) {
-                block = next_own++;
-            } else {
-                if (!POOL_SHARE) break;
-                phase = 1;
-                ahead = claim_block(b, wave);
-                continue;
-            }
-        } else if (phase == 1) {
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
-            if (pool0 + c >= n_blocks) {
-                // the region's pool is used up (every wave that finds it so says so; the owner always gets here, so the
-                // map is all zeros again when the kernel ends)
-                if (lane == 0 && n_blocks > pool0) atomicAnd(&b.pool_map[wave >> 6], ~(1ull << (wave & 63u)));
-                phase = 2;
-                continue;
-            }
-            ahead = claim_block(b, wave);
-            block = pool0 + c;
-        } else if (got_next < got_end) {
-            src = got_src; src_total = got_total; block = got_next++;
-        } else {
-            // only while this wave's regions can take all the paths of the blocks of another claim (what goes to the probe
-            // regions may come on to the next extend region), and not for ever: near the end many waves look for the same few blocks
-            if (failed >= STEAL_TRIES || fill.next + fill.shadow + fill.glossy + 64u * STEAL_BLOCKS > b.region_cap) break;
-            // b.pool_map: one bit per region whose pool may have blocks left (lane l reads the word of regions 64 l ...).  The
-            // words change under way: read past this XCD's L2, which may hold an old value for as long as it likes.
-            const unsigned long long word = __hip_atomic_load(&b.pool_map[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long lanes = __builtin_amdgcn_ballot_w64(word != 0ull);
-            if (lanes == 0ull) break;
-            // a set bit picked by a number that differs from wave to wave and from try to try, so that the idle waves spread
-            // over the regions that have work left
-            pick = pick * 1664525u + 1013904223u;
-            const uint32_t r1 = (pick >> 8) & 63u, r2 = (pick >> 16) & 63u;
-            const unsigned long long lanes_rot = (lanes >> r1) | (r1 ? lanes << (64u - r1) : 0ull);
-            const uint32_t l = ((uint32_t)__builtin_ctzll(lanes_rot) + r1) & 63u;
-            const unsigned long long w = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)word, (int)l) |
-                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(word >> 32), (int)l) << 32);
-            const unsigned long long w_rot = (w >> r2) | (r2 ? w << (64u - r2) : 0ull);
-            src = l * 64u + (((uint32_t)__builtin_ctzll(w_rot) + r2) & 63u);
-            src_total = (uint32_t)__builtin_amdgcn_readfirstlane((int)counts[src]);
-            const uint32_t nb = (src_total + 63u) >> 6;
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)claim_block(b, src, STEAL_BLOCKS));
-            if (pool_first_block(nb) + c >= nb) {       // used up: another wave was faster
-                if (lane == 0) atomicAnd(&b.pool_map[src >> 6], ~(1ull << (src & 63u)));
-                failed++;
-                continue;
-            }
-            block = pool_first_block(nb) + c;
-            got_src = src; got_total = src_total; got_next = block + 1u;
-            got_end = block + STEAL_BLOCKS < nb ? block + STEAL_BLOCKS : nb;
-        }
+        // foreign blocks only while this wave's regions can take all their paths (what goes to the probe regions may come
+        // on to the next extend region)
+        uint32_t src, src_total, block;
+        if (!feed_next(feed, b, fill.next + fill.shadow + fill.glossy + 64u * STEAL_BLOCKS <= b.region_cap, src, src_total, block)) break;
         const uint32_t qi = block * 64u + lane;
         const bool live = qi < src_total;
         uint32_t id = 0, kept_flags = 0;
@@ -631,6 +664,14 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
         wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
     }
 }
+
+// Depth-0 chunks with fewer probes than this leave them to the probe stages of depth 0 (PipeBuffers::defer_below); scenes
+// from DEFER_MAX_TRIANGLES triangles on do not (their probe searches are long whatever the lanes' neighbours do).
+#ifndef RT_DEFER_BELOW
+#define RT_DEFER_BELOW 32
+#endif
+constexpr uint32_t DEFER_BELOW = RT_DEFER_BELOW;
+constexpr int DEFER_MAX_TRIANGLES = 65536;
 
 // Depth 0 in one kernel: camera ray, closest hit, shading, the bounce's light probe and the rest of the bounce.
 // At depth 0 the 64 lanes of a wave are the pixels of one 8x8 tile of one sample, so they all draw the same
@@ -654,6 +695,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
     uint32_t n_paths = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
+    uint32_t q_shadow = 0, q_glossy = 0;       // probes left to the probe stages of depth 0 (DEFER_BELOW)
     const bool deeper = 1 < max_depth;
 
 #if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS > 0
@@ -704,7 +746,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     for (;;) {
         uint32_t chunk;
         if (round < fixed_rounds) {
-            if (fill_next + 64u > b.region_cap) { stalled = true; break; }
+            if (fill_next + q_shadow + q_glossy + 64u > b.region_cap) { stalled = true; break; }
             chunk = round * (uint32_t)PIPE_WAVES + first;
             round++;
         } else {
@@ -717,7 +759,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
                     enter_part();
                     continue;
                 }
-                if (fill_next + 64u > b.region_cap) { stalled = true; break; }        // this wave's region cannot take another chunk whole
+                if (fill_next + q_shadow + q_glossy + 64u > b.region_cap) { stalled = true; break; }        // this wave's regions cannot take another chunk whole
                 c = (uint32_t)__builtin_amdgcn_readfirstlane((int)take());
             }
             have_ahead = false;
@@ -727,7 +769,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
                 continue;
             }
             // the next one is asked for now if the region holds this chunk and the next whatever survives
-            have_ahead = fill_next + 128u <= b.region_cap;
+            have_ahead = fill_next + q_shadow + q_glossy + 128u <= b.region_cap;
             if (have_ahead) ahead = take();
             const uint32_t block_in_run = c / CHUNK_BLOCK;
             chunk = fixed_chunks + (block_in_run * N_RUNS + run_x) * CHUNK_BLOCK + (c - block_in_run * CHUNK_BLOCK);
@@ -775,6 +817,21 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
         uint32_t kept_flags = 0;
         bool go_on = false;
+        // A chunk with few probes (a tile at the edge of an object) would run the search with most lanes idle: its probes
+        // are left to the probe stages of depth 0, which run them packed with those of other chunks.
+        bool deferred = false;
+        if (b.defer_below) {
+            const bool wants = shaded && bn.kind == (coin_diffuse ? PROBE_SHADOW : PROBE_GLOSSY);
+            const uint32_t n_wants = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wants));
+            // (only while the wave's regions are at most 7/8 full: these records must not be what makes a pass need a further round)
+            if (n_wants != 0u && n_wants < b.defer_below && 8u * (fill_next + q_shadow + q_glossy + 64u) <= 7u * b.region_cap) {
+                deferred = wants;
+                const size_t region = (size_t)wave * b.region_cap;
+                const uint32_t slot = region_slot(coin_diffuse ? q_shadow : q_glossy, wants);
+                if (wants) store_probe_rec(b, coin_diffuse ? region + slot : region + (b.region_cap - 1u - slot), ps, id, hit, 0u, bn, coin_diffuse);
+                shaded = shaded && !wants;       // the probe stage goes on with these paths
+            }
+        }
         if (coin_diffuse) {
             const bool run = shaded && bn.kind == PROBE_SHADOW;
             bool blocked = true;
@@ -807,12 +864,12 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
                 }
             }
         }
-        route_next(b, 1, fill_next, live, go_on, ps, id, kept_flags);
+        route_next(b, 1, fill_next, live && !deferred, go_on, ps, id, kept_flags);
         SECTION_MARK(3);
     }
     if (lane == 0) {
-        b.n_shadow[wave] = 0;
-        b.n_glossy[wave] = 0;
+        b.n_shadow[wave] = q_shadow;
+        b.n_glossy[wave] = q_glossy;
         b.n_ext[1][wave] = fill_next;
         b.resume[wave] = round;
         if (stalled) more_flags(b.work)[b.round] = 1u;
@@ -1038,13 +1095,18 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     stage_hierarchies<CFG>(bv, bv, false, stack_mem, scene_mem, share_mem, ws, lws, share);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
-    const size_t region = (size_t)wave * b.region_cap;
-    const uint32_t total = b.n_shadow[wave];
-    uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
+    uint32_t fill_next = b.n_ext[q_in ^ 1][wave], n_done = 0;
+    const uint32_t fill0 = fill_next, own_glossy = b.n_glossy[wave];
     const bool deeper = depth + 1 < max_depth;
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const bool live = base + lane < total;
-        const size_t i = region + (live ? base + lane : 0u);
+    BlockFeed feed;
+    feed_begin(feed, b, b.n_shadow, b.claim + PIPE_WAVES, PROBE_POOL_SHARE);
+    for (;;) {
+        // foreign blocks only while the next extend region can take their paths on top of this wave's own glossy probes
+        uint32_t src, src_total, block;
+        if (!feed_next(feed, b, fill_next + own_glossy + 64u * STEAL_BLOCKS <= b.region_cap, src, src_total, block)) break;
+        const bool live = block * 64u + lane < src_total;
+        const size_t i = (size_t)src * b.region_cap + (live ? block * 64u + lane : 0u);
+        n_done += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         ProbeHead h;
         load_probe_head(b, i, h);
         const bool blocked = shadow_any_hit_cfg<CFG>(sc, bv, h.probe, h.max_t, h.current, live, ws, share, bc);
@@ -1054,8 +1116,12 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
         if (live) go_on = retire_shadow(sc, b, i, h, blocked, deeper, ps, kept_flags);
         route_next(b, q_in ^ 1, fill_next, live, go_on, ps, h.id, kept_flags);
     }
-    if (lane == 0) b.n_ext[q_in ^ 1][wave] = fill_next;
-    wstat_add(b, WSTAT_SHADOW, total);
+    if (depth == 0) wstat_add(b, WSTAT_DEPTH1, fill_next - fill0);
+    if (lane == 0) {
+        b.n_ext[q_in ^ 1][wave] = fill_next;
+        b.claim[2 * PIPE_WAVES + wave] = 0;      // the glossy stage's counters: used by the launch after this one
+    }
+    wstat_add(b, WSTAT_SHADOW, n_done);
     if (CFG::BVH) {
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
         wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(bc.tris));
@@ -1074,14 +1140,18 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     stage_hierarchies<CFG>(bv, lbv, true, stack_mem, scene_mem, share_mem, ws, lws, share);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
-    const size_t region = (size_t)wave * b.region_cap;
-    const size_t last = region + b.region_cap - 1u;
-    const uint32_t total = b.n_glossy[wave];
-    uint32_t fill_next = b.n_ext[q_in ^ 1][wave];
+    uint32_t fill_next = b.n_ext[q_in ^ 1][wave], n_done = 0;
+    const uint32_t fill0 = fill_next;
     const bool deeper = depth + 1 < max_depth;
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const bool live = base + lane < total;
-        const size_t i = last - (live ? base + lane : 0u);
+    BlockFeed feed;
+    feed_begin(feed, b, b.n_glossy, b.claim + 2 * PIPE_WAVES, PROBE_POOL_SHARE);
+    for (;;) {
+        uint32_t src, src_total, block;
+        if (!feed_next(feed, b, fill_next + 64u * STEAL_BLOCKS <= b.region_cap, src, src_total, block)) break;
+        const bool live = block * 64u + lane < src_total;
+        // glossy records fill a region from its back
+        const size_t i = (size_t)src * b.region_cap + (b.region_cap - 1u) - (live ? block * 64u + lane : 0u);
+        n_done += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         ProbeHead h;
         load_probe_head(b, i, h);
         int light_id;
@@ -1093,11 +1163,14 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
         if (live) go_on = retire_glossy(sc, fr, b, i, h, outcome, light_id, lsec, deeper, ps, kept_flags);
         route_next(b, q_in ^ 1, fill_next, live, go_on, ps, h.id, kept_flags);
     }
+    if (depth == 0) wstat_add(b, WSTAT_DEPTH1, fill_next - fill0);
     if (lane == 0) {
         b.n_ext[q_in ^ 1][wave] = fill_next;
-        b.claim[wave] = 0;          // used by the extend stage before this one, and by the next
+        // the counters of the extend and of the shadow stage: used before this launch, and by the next ones
+        b.claim[wave] = 0;
+        b.claim[PIPE_WAVES + wave] = 0;
     }
-    wstat_add(b, WSTAT_GLOSSY, total);
+    wstat_add(b, WSTAT_GLOSSY, n_done);
     if (CFG::BVH) {
         wstat_add(b, WSTAT_PROBE_NODES, wave_sum_u32(bc.nodes));
         wstat_add(b, WSTAT_PROBE_TRIS, wave_sum_u32(bc.tris));
@@ -1279,9 +1352,9 @@ struct Pipeline {
             PIPE_ALLOC(buf.n_glossy, sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.work, sizeof(uint32_t) * (N_RUNS + MAX_ROUNDS + 1));
             PIPE_ALLOC(buf.resume, sizeof(uint32_t) * (PIPE_WAVES + 1));
-            PIPE_ALLOC(buf.claim, sizeof(uint32_t) * PIPE_WAVES);
+            PIPE_ALLOC(buf.claim, sizeof(uint32_t) * 3 * PIPE_WAVES);
             *what = "memset claim";
-            e = hipMemset(buf.claim, 0, sizeof(uint32_t) * PIPE_WAVES);
+            e = hipMemset(buf.claim, 0, sizeof(uint32_t) * 3 * PIPE_WAVES);
             if (e != hipSuccess) goto failed;
             PIPE_ALLOC(buf.pool_map, sizeof(unsigned long long) * (PIPE_WAVES / 64));
             *what = "memset pool_map";
@@ -1418,10 +1491,19 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
         // launches of the rounds after the first are timed with the others but not counted as launches (most return at once)
         buf.round = round;
         buf.rounds = rounds;
+        buf.defer_below = (CFG::BVH && sc.count < DEFER_MAX_TRIANGLES) ? DEFER_BELOW : 0u;
         PIPE_TRY(stamp(round == 0 ? 3 : 4));
         if (round == 0) hipLaunchKernelGGL((k_first<CFG, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
         else hipLaunchKernelGGL((k_first<CFG, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
         PIPE_TRY(hipGetLastError());
+        if (buf.defer_below) {
+            // the probes that k_first left to the probe stages (chunks with few of them); survivors join queue 1
+            PIPE_TRY(stamp(round == 0 ? 1 : 6));
+            hipLaunchKernelGGL(k_probe_shadow<CFG>, grid, block, 0, stream, sc, bvh, buf, 0, 0, max_depth);
+            PIPE_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_probe_glossy<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, 0, 0, max_depth);
+            PIPE_TRY(hipGetLastError());
+        }
         PIPE_TRY(stamp(-1));
         int q_in = 1;
         for (int depth = 1; depth < staged_end; depth++) {
