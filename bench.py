@@ -307,9 +307,11 @@ def main():
         used_bvh = args.accel != 0 and len(scene[0]) >= 64
         if used_bvh:
             # Nodes and triangles come from LDS/L1/L2; what has to cross HBM is what the stage leaves behind: a 12-byte
-            # radiance record per path that ended, a 64-byte path record per path that goes on.
-            d1 = float(st["depth1_paths"])
-            algo = (float(st["pixel_samples"]) - d1) * 12.0 + d1 * 64.0
+            # radiance record per path that ended, a 64-byte path record per path that goes on (depth1_paths counts those,
+            # the ones among the deferred probes included: an upper bound by that much), a 112-byte probe record per
+            # probe left to the probe kernels.
+            d1, dp = float(st["depth1_paths"]), float(st["deferred_probes"])
+            algo = (float(st["pixel_samples"]) - d1 - dp) * 12.0 + d1 * 64.0 + dp * 112.0
             achieved = algo / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
             prof, provenance = profile_counters(args.workload, "k_first<")
             comparable = prof is not None and args.spp_per_step == SPP_PER_STEP and (W, H) == (1920, 1080)

@@ -28,7 +28,8 @@ class RtStats(ctypes.Structure):
                 ("probe_launches", ctypes.c_uint64), ("extend0_ms", ctypes.c_double),
                 ("extend0_launches", ctypes.c_uint64), ("bvh_extend_nodes", ctypes.c_uint64),
                 ("bvh_extend_tris", ctypes.c_uint64), ("bvh_probe_nodes", ctypes.c_uint64),
-                ("bvh_probe_tris", ctypes.c_uint64), ("depth1_paths", ctypes.c_uint64), ("queue_bytes", ctypes.c_uint64)]
+                ("bvh_probe_tris", ctypes.c_uint64), ("depth1_paths", ctypes.c_uint64), ("queue_bytes", ctypes.c_uint64),
+                ("deferred_probes", ctypes.c_uint64)]
 
 
 class GpuRtError(RuntimeError):

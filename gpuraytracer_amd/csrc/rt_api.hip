@@ -817,6 +817,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     s.bvh_probe_nodes = ds.probe_nodes;
     s.bvh_probe_tris = ds.probe_tris;
     s.depth1_paths = ws[WSTAT_DEPTH1];
+    s.deferred_probes = ws[WSTAT_DEFERRED];
     s.queue_bytes = ctx->pipe.queue_bytes();
     *out = s;
     return RT_OK;

@@ -302,7 +302,7 @@ struct PipeBuffers {
 };
 
 enum { WSTAT_PATHS = 0, WSTAT_RAYS, WSTAT_SHADOW, WSTAT_GLOSSY, WSTAT_EXT_NODES, WSTAT_EXT_TRIS, WSTAT_PROBE_NODES,
-       WSTAT_PROBE_TRIS, WSTAT_DEPTH1, WSTAT_SLOTS = 16 };
+       WSTAT_PROBE_TRIS, WSTAT_DEPTH1, WSTAT_DEFERRED, WSTAT_SLOTS = 16 };
 
 constexpr uint32_t KEPT_DIFF = 1u, KEPT_SPEC = 2u;      // kept flags
 constexpr uint32_t CURRENT_MASK = 0x3FFFFFFFu;
@@ -878,6 +878,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     wstat_add(b, WSTAT_PATHS, n_paths);
     wstat_add(b, WSTAT_RAYS, n_paths);
     wstat_add(b, WSTAT_DEPTH1, fill_next);
+    wstat_add(b, WSTAT_DEFERRED, q_shadow + q_glossy);
     wstat_add(b, WSTAT_SHADOW, n_shadow);
     wstat_add(b, WSTAT_GLOSSY, n_glossy);
 #if RT_SECTION_CLOCKS > 0

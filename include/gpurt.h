@@ -83,6 +83,7 @@ typedef struct rt_stats {
     uint64_t bvh_extend_nodes, bvh_extend_tris, bvh_probe_nodes, bvh_probe_tris;
     uint64_t depth1_paths;      /* camera paths that went on to a second bounce (staged form; else 0) */
     uint64_t queue_bytes;       /* device memory the path queues of the staged form hold at present */
+    uint64_t deferred_probes;   /* light probes of depth 0 that the depth-0 kernel left to the probe kernels (as 112-byte records) */
 } rt_stats;
 
 typedef struct rt_context rt_context;
