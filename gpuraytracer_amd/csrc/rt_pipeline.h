@@ -18,7 +18,12 @@
 //   resolve  adds the radiance of the batch's paths to the per-pixel sums in ascending sample order
 //
 // The launch sequence of a pass is fixed (no decision needs a value read back from the device: a stage whose
-// queue region is empty ends at once), so rt_trace only enqueues work and can be captured in a HIP graph.
+// queue region is empty ends at once), so rt_trace only enqueues work and can be captured in a HIP graph:
+//   rounds x ( first, [shadow, glossy of depth 0: the probes of chunks that had too few to run them in place],
+//              staged depths x ( extend, shadow, glossy ), tail ), resolve
+// The queues hold a fraction of a pass; a pass whose survivors do not fit goes on in the next round (MAX_ROUNDS), and
+// the kernels of a round that has nothing to do return on their first instruction.  The extend and probe stages take
+// their records in blocks of 64, part of them from pools that any wave may draw on (BlockFeed).
 //
 // A queue entry is the path's whole state (a record), not an index into a state array: the survivors of a
 // bounce are a sparse subset of the paths, and gathering 16-byte fields of every fifth path from planes
