@@ -214,6 +214,8 @@ def test_full_size_forms_agree(gpu_ctx, oracle_mod, cubes):
     for k in ("pixel_samples", "rays", "shadow_probes", "glossy_probes"):
         assert sa[k] == sb[k] == sc_[k], k
     assert sa["pixel_samples"] == 1920 * 1080 * 8
+    # the staged form leaves the probes of sparse depth-0 chunks to the probe kernels, the single kernel has no queues
+    assert sa["deferred_probes"] > 0 and sb["deferred_probes"] == 0
     sc = oracle_mod.OracleScene(*cubes)
     sc.upload_env(constant_env())
     want, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 1920, 1080, 0, 1)
