@@ -56,6 +56,239 @@ struct Reader {
 
 struct Channel { std::string name; int type; };
 
+// ---- PIZ blocks -------------------------------------------------------------------------------------------------
+// OpenEXR's PIZ coder works on the 16-bit words of a block (a FLOAT sample is two words, low word first), gathered
+// channel by channel: the words are renumbered densely through a bitmap of the values in use, each channel plane is
+// transformed by a two-dimensional Haar-like wavelet, and the result is written with a canonical Huffman code whose
+// table is a list of 6-bit code lengths; one extra symbol (the largest one) means "repeat the last word k times",
+// k in the next 8 bits. Decoding runs the three steps backwards. This follows the published format of the OpenEXR
+// library (the reference reads its textures through tinyexr's LoadEXR, Scene.cpp:163, which accepts such files).
+
+constexpr uint32_t PIZ_SYMBOLS = 65537;        // 65536 word values and the repeat symbol
+constexpr int PIZ_MAX_CODE = 58;               // longest code; lengths 59..63 in the table are runs of unused symbols
+constexpr int PIZ_PEEK = 14;                   // codes up to this length resolve through one table look-up
+
+struct HuffmanCode {
+    uint64_t first[PIZ_MAX_CODE + 1] = {};     // value of the first code of each length
+    uint32_t count[PIZ_MAX_CODE + 1] = {};     // symbols of each length
+    uint32_t start[PIZ_MAX_CODE + 2] = {};     // where a length's symbols begin in `symbols`
+    std::vector<uint32_t> symbols;             // by length, then by value: the order codes are handed out in
+    std::vector<uint32_t> peek;                // 2^PIZ_PEEK entries: symbol << 6 | length, 0 = longer code or none
+};
+
+// Reads the table of code lengths for symbols lo..hi (bit stream, most significant bit first) and derives the codes:
+// the longest codes start at 0, each shorter length continues at half the value the longer one ended at, and symbols
+// of one length take consecutive codes in ascending order. Returns the bytes the table took, 0 on error.
+size_t piz_read_code(const uint8_t *p, size_t n, uint32_t lo, uint32_t hi, HuffmanCode &hc) {
+    std::vector<uint8_t> len(PIZ_SYMBOLS, 0);
+    size_t at = 0;
+    uint64_t acc = 0;
+    int have = 0;
+    auto bits = [&](int k, uint32_t &v) {
+        while (have < k) {
+            if (at >= n) return false;
+            acc = (acc << 8) | p[at++];
+            have += 8;
+        }
+        have -= k;
+        v = (uint32_t)(acc >> have) & ((1u << k) - 1u);
+        return true;
+    };
+    for (uint32_t s = lo; s <= hi;) {
+        uint32_t l;
+        if (!bits(6, l)) return 0;
+        if (l <= (uint32_t)PIZ_MAX_CODE) { len[s++] = (uint8_t)l; continue; }
+        uint32_t run = l - 57;                                   // 59..62: 2..5 unused symbols
+        if (l == 63) { if (!bits(8, run)) return 0; run += 6; }  // 63: 6..261 of them, count in the next byte
+        if ((uint64_t)s + run > (uint64_t)hi + 1) return 0;
+        s += run;
+    }
+    for (uint32_t s = 0; s < PIZ_SYMBOLS; s++) hc.count[len[s]]++;
+    hc.count[0] = 0;
+    uint64_t next = 0;
+    for (int l = PIZ_MAX_CODE; l >= 1; l--) {
+        hc.first[l] = next;
+        next = (next + hc.count[l]) >> 1;
+    }
+    for (int l = 1; l <= PIZ_MAX_CODE; l++) {
+        hc.start[l + 1] = hc.start[l] + hc.count[l];
+        if (hc.count[l] && ((hc.first[l] + hc.count[l] - 1) >> l)) return 0;   // more codes than the length has
+    }
+    hc.symbols.resize(hc.start[PIZ_MAX_CODE + 1]);
+    {
+        uint32_t fill[PIZ_MAX_CODE + 2];
+        memcpy(fill, hc.start, sizeof(fill));
+        for (uint32_t s = 0; s < PIZ_SYMBOLS; s++)
+            if (len[s]) hc.symbols[fill[len[s]]++] = s;
+    }
+    hc.peek.assign((size_t)1 << PIZ_PEEK, 0u);
+    for (int l = 1; l <= PIZ_PEEK; l++)
+        for (uint32_t k = 0; k < hc.count[l]; k++) {
+            const uint32_t entry = (hc.symbols[hc.start[l] + k] << 6) | (uint32_t)l;
+            const size_t from = (size_t)(hc.first[l] + k) << (PIZ_PEEK - l);
+            std::fill(hc.peek.begin() + from, hc.peek.begin() + from + ((size_t)1 << (PIZ_PEEK - l)), entry);
+        }
+    return at;
+}
+
+// The Huffman layer: a 20-byte header (smallest and largest symbol in the table, the table's byte length, the number
+// of code bits, a reserved word), the table, the codes.
+const char *piz_huffman_decode(const uint8_t *src, size_t n, uint16_t *out, size_t n_out) {
+    if (n == 0) return n_out ? "PIZ: no data" : nullptr;
+    if (n < 20) return "PIZ: truncated Huffman header";
+    uint32_t lo, hi, nbits32;
+    memcpy(&lo, src, 4); memcpy(&hi, src + 4, 4); memcpy(&nbits32, src + 12, 4);
+    if (lo >= PIZ_SYMBOLS || hi >= PIZ_SYMBOLS) return "PIZ: bad symbol range";
+    HuffmanCode hc;
+    const size_t table = piz_read_code(src + 20, n - 20, lo, hi, hc);
+    if (!table && lo <= hi) return "PIZ: bad code table";
+    const uint8_t *d = src + 20 + table;
+    const uint64_t avail = (uint64_t)(n - 20 - table) * 8, nbits = nbits32;
+    if (nbits > avail) return "PIZ: fewer code bits than announced";
+    const size_t nbytes = (size_t)((nbits + 7) / 8);
+    auto window = [&](uint64_t pos, int k) {        // k <= 16 bits from bit `pos` on, zeros past the end
+        const size_t b = (size_t)(pos >> 3);
+        uint32_t w = 0;
+        for (size_t i = 0; i < 3; i++) w = (w << 8) | (b + i < nbytes ? d[b + i] : 0u);
+        return (w >> (24 - k - (int)(pos & 7))) & ((1u << k) - 1u);
+    };
+    const uint32_t repeat = hi;
+    uint64_t pos = 0;
+    size_t o = 0;
+    while (pos < nbits) {
+        uint32_t sym = 0;
+        int l;
+        const uint32_t head = window(pos, PIZ_PEEK), e = hc.peek[head];
+        if (e) { sym = e >> 6; l = (int)(e & 63u); }
+        else {
+            uint64_t code = head;
+            bool found = false;
+            for (l = PIZ_PEEK + 1; l <= PIZ_MAX_CODE && pos + (uint64_t)l <= nbits; l++) {
+                code = (code << 1) | window(pos + (uint64_t)l - 1, 1);
+                if (code >= hc.first[l] && code - hc.first[l] < hc.count[l]) {
+                    sym = hc.symbols[hc.start[l] + (size_t)(code - hc.first[l])];
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) return "PIZ: bad code";
+        }
+        if (pos + (uint64_t)l > nbits) return "PIZ: code runs past the end";
+        pos += (uint64_t)l;
+        if (sym == repeat) {
+            if (pos + 8 > nbits) return "PIZ: repeat count runs past the end";
+            const uint32_t k = window(pos, 8);
+            pos += 8;
+            if (o == 0 || o + k > n_out) return "PIZ: bad repeat";
+            for (uint32_t i = 0; i < k; i++, o++) out[o] = out[o - 1];
+        } else {
+            if (o >= n_out) return "PIZ: more words than the block holds";
+            out[o++] = (uint16_t)sym;
+        }
+    }
+    return o == n_out ? nullptr : "PIZ: fewer words than the block holds";
+}
+
+// One wavelet step backwards: (average, difference) -> the two values. With fewer than 2^14 values in use the words
+// are treated as signed and nothing can overflow; otherwise the arithmetic is modulo 2^16 around an offset of 2^15.
+inline void piz_unstep(bool small, uint16_t avg, uint16_t diff, uint16_t &a, uint16_t &b) {
+    if (small) {
+        const int d = (int16_t)diff, x = (int16_t)avg + (d & 1) + (d >> 1);
+        a = (uint16_t)x;
+        b = (uint16_t)(x - d);
+    } else {
+        const int bb = ((int)avg - ((int)diff >> 1)) & 0xFFFF;
+        a = (uint16_t)(((int)diff + bb - 0x8000) & 0xFFFF);
+        b = (uint16_t)bb;
+    }
+}
+
+// Undoes the wavelet transform of one plane of nx x ny words (ox, oy: distance between neighbours in x and in y),
+// from the coarsest level down: each level combines words `half` apart inside cells `cell` = 2 * half wide, 2 x 2 at a
+// time, and by pairs along the last column / row when the plane's size has that bit set.
+void piz_wavelet_decode(uint16_t *w, int nx, int ox, int ny, int oy, uint32_t max_value) {
+    const bool small = max_value < (1u << 14);
+    const int n = std::min(nx, ny);
+    int cell = 1;
+    while (cell * 2 <= n) cell *= 2;
+    for (int half = cell / 2; half >= 1; cell = half, half /= 2) {
+        const long dx = (long)ox * half, dy = (long)oy * half;
+        int y = 0;
+        for (; y + cell <= ny; y += cell) {
+            int x = 0;
+            for (; x + cell <= nx; x += cell) {
+                uint16_t *p00 = w + (long)y * oy + (long)x * ox, *p01 = p00 + dx, *p10 = p00 + dy, *p11 = p10 + dx;
+                uint16_t t00, t01, t10, t11;
+                piz_unstep(small, *p00, *p10, t00, t10);
+                piz_unstep(small, *p01, *p11, t01, t11);
+                piz_unstep(small, t00, t01, *p00, *p01);
+                piz_unstep(small, t10, t11, *p10, *p11);
+            }
+            if (nx & half) {
+                uint16_t *p00 = w + (long)y * oy + (long)x * ox, *p10 = p00 + dy, a, b;
+                piz_unstep(small, *p00, *p10, a, b);
+                *p00 = a; *p10 = b;
+            }
+        }
+        if (ny & half)
+            for (int x = 0; x + cell <= nx; x += cell) {
+                uint16_t *p00 = w + (long)y * oy + (long)x * ox, *p01 = p00 + dx, a, b;
+                piz_unstep(small, *p00, *p01, a, b);
+                *p00 = a; *p01 = b;
+            }
+    }
+}
+
+// A whole PIZ block of cols x rows pixels into `out` (the uncompressed layout: row by row, channel by channel).
+const char *piz_decode(const uint8_t *src, size_t size, const std::vector<Channel> &chans, int cols, int rows,
+                       uint8_t *out, size_t want) {
+    if (size < 4) return "PIZ: truncated block";
+    uint16_t lo, hi;
+    memcpy(&lo, src, 2); memcpy(&hi, src + 2, 2);
+    size_t at = 4;
+    std::vector<uint8_t> used(8192, 0);                 // bit v set: word value v occurs; value 0 is always in use
+    if (hi >= used.size()) return "PIZ: bad bitmap range";
+    if (lo <= hi) {
+        const size_t len = (size_t)hi - lo + 1;
+        if (size - at < len) return "PIZ: truncated bitmap";
+        memcpy(used.data() + lo, src + at, len);
+        at += len;
+    }
+    std::vector<uint16_t> value_of(65536, 0);           // dense number -> word value
+    uint32_t n_values = 0;
+    for (uint32_t v = 0; v < 65536; v++)
+        if (v == 0 || (used[v >> 3] & (1u << (v & 7)))) value_of[n_values++] = (uint16_t)v;
+    if (size - at < 4) return "PIZ: truncated block";
+    int32_t len;
+    memcpy(&len, src + at, 4);
+    at += 4;
+    if (len < 0 || (size_t)len > size - at) return "PIZ: bad length";
+    const size_t words = want / 2;
+    std::vector<uint16_t> w(words);
+    if (const char *what = piz_huffman_decode(src + at, (size_t)len, w.data(), words)) return what;
+    size_t plane = 0;
+    for (const Channel &c : chans) {
+        const int per = c.type == 1 ? 1 : 2;
+        for (int j = 0; j < per; j++) piz_wavelet_decode(w.data() + plane + j, cols, per, rows, cols * per, n_values - 1);
+        plane += (size_t)cols * rows * per;
+    }
+    for (uint16_t &v : w) v = value_of[v];
+    std::vector<size_t> row_of(chans.size());
+    plane = 0;
+    for (size_t c = 0; c < chans.size(); c++) {
+        row_of[c] = plane;
+        plane += (size_t)cols * rows * (chans[c].type == 1 ? 1 : 2);
+    }
+    for (int y = 0; y < rows; y++)
+        for (size_t c = 0; c < chans.size(); c++) {
+            const size_t n = (size_t)cols * (chans[c].type == 1 ? 1 : 2);
+            memcpy(out, w.data() + row_of[c], n * 2);
+            out += n * 2;
+            row_of[c] += n;
+        }
+    return nullptr;
+}
+
 }  // namespace
 
 bool writeEXR(const std::string &path, int width, int height, int channels, const float *pixels, std::string *err) {
@@ -155,7 +388,7 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
         r.p += size;
     }
     if (!r.ok || chans.empty() || xmax < xmin || ymax < ymin) return fail("bad header");
-    if (compression < 0 || compression > 3) return fail("compression must be NONE, RLE, ZIPS or ZIP");
+    if (compression < 0 || compression > 4) return fail("compression must be NONE, RLE, ZIPS, ZIP or PIZ");
     if (tiled && (tile_w == 0 || tile_h == 0)) return fail("tiled file without a tile description");
     if (tiled && (tile_mode & 0xFu) != 0) return fail("only tiled files with one level are supported");
     width = xmax - xmin + 1;
@@ -177,6 +410,8 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
         if (compression == 0 || size == want) {
             if (size != want) return "bad block size";
             memcpy(raw.data(), src, want);
+        } else if (compression == 4) {
+            if (const char *what = piz_decode(src, size, chans, cols, rows, raw.data(), want)) return what;
         } else {
             tmp.resize(want);
             if (compression == 1) {
@@ -243,7 +478,7 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
         }
         return true;
     }
-    const int lines_per_block = compression == 3 ? 16 : 1;
+    const int lines_per_block = compression == 4 ? 32 : compression == 3 ? 16 : 1;
     const int blocks = (height + lines_per_block - 1) / lines_per_block;
     std::vector<uint64_t> offsets(blocks);
     for (int i = 0; i < blocks; i++) offsets[i] = r.u64();

@@ -258,6 +258,130 @@ def test_exr_reader_tiled(tmp_path, compression):
     assert np.array_equal(back[..., :3], img) and (back[..., 3] == 1).all()
 
 
+def _piz_exr(path, img, types, tile=None, stats=None):
+    """Writes a PIZ-compressed EXR with Python (tests/exr_piz.py): img is (h, w, 3 or 4) RGB(A), `types` gives each
+    channel's sample type (1 = HALF, 2 = FLOAT) by name; scanline blocks of 32 lines, or tiles of `tile` = (w, h)."""
+    from exr_piz import piz_block
+    h, w, nc = img.shape
+    names = ("A", "B", "G", "R") if nc == 4 else ("B", "G", "R")
+    src = {"R": 0, "G": 1, "B": 2, "A": 3}
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
+    ch = b"".join(n.encode() + b"\0" + struct.pack("<IBBBBII", types[n], 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr = struct.pack("<II", 20000630, 2 | (0x200 if tile else 0)) + attr("channels", "chlist", ch)
+    hdr += attr("compression", "compression", bytes([4]))
+    hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
+    hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    if tile:
+        hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tile[0], tile[1], 0))
+    hdr += b"\0"
+
+    def block(part):
+        planes = []
+        for n in names:
+            v = np.ascontiguousarray(part[:, :, src[n]])
+            if types[n] == 1:
+                planes.append((v.astype("<f2").view(np.uint16), 1))
+            else:
+                planes.append((v.astype("<f4").view(np.uint16), 2))
+        return piz_block(planes, stats)
+    chunks = []
+    if tile:
+        for ty in range((h + tile[1] - 1) // tile[1]):
+            for tx in range((w + tile[0] - 1) // tile[0]):
+                data = block(img[ty * tile[1]:(ty + 1) * tile[1], tx * tile[0]:(tx + 1) * tile[0]])
+                chunks.append(struct.pack("<iiiii", tx, ty, 0, 0, len(data)) + data)
+    else:
+        for y0 in range(0, h, 32):
+            data = block(img[y0:y0 + 32])
+            chunks.append(struct.pack("<ii", y0, len(data)) + data)
+    off = len(hdr) + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", off)
+        off += len(c)
+    with open(path, "wb") as fh:
+        fh.write(hdr + table + b"".join(chunks))
+
+
+def _piz_test_image(rng, h, w, nc):
+    """Smooth ramps, flat areas and a patch of noise: few distinct words per block, long runs after the wavelet."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([(x + 2 * y) / 64, np.sin(x / 9) * np.cos(y / 7) + 1, (x * y) / 512, 0.5 + 0 * x][:nc], axis=-1)
+    img = img.astype(np.float16).astype(np.float32)                  # the same values whether stored HALF or FLOAT
+    img[5:9, 3:15] = 0.75
+    img[h // 2:, :w // 3] = 0.0
+    img[2:12, w - 12:w - 2] = rng.uniform(0, 2, size=(10, 10, nc)).astype(np.float16)
+    return img
+
+
+def test_exr_reader_piz_half_scanlines(tmp_path):
+    rng = np.random.default_rng(5)
+    img = _piz_test_image(rng, 71, 53, 3)                            # blocks of 32, 32 and 7 lines, odd sizes
+    stats = {}
+    p = str(tmp_path / "p.exr")
+    _piz_exr(p, img, {"R": 1, "G": 1, "B": 1}, stats=stats)
+    assert stats["coded_blocks"] == 3 and stats["repeats"] > 0 and stats["max_value"] < (1 << 14)
+    back = host.read_exr(p)
+    assert back.shape == (71, 53, 4)
+    assert np.array_equal(back[..., :3], img) and (back[..., 3] == 1).all()
+
+
+def test_exr_reader_piz_mixed_types_and_one_line(tmp_path):
+    rng = np.random.default_rng(6)
+    img = _piz_test_image(rng, 33, 40, 4)                            # second block is a single line: no wavelet level
+    p = str(tmp_path / "p.exr")
+    _piz_exr(p, img, {"R": 2, "G": 2, "B": 2, "A": 1})
+    assert np.array_equal(host.read_exr(p), img)
+    flat = np.zeros((3, 5, 3), np.float32)                           # only the word 0 in use: empty bitmap
+    _piz_exr(p, flat, {"R": 1, "G": 1, "B": 1})
+    assert np.array_equal(host.read_exr(p)[..., :3], flat)
+
+
+def test_exr_reader_piz_many_values_tiled(tmp_path):
+    """More than 2^14 distinct words in a tile: the wavelet's modulo-2^16 form, and codes longer than 14 bits."""
+    rng = np.random.default_rng(7)
+    img = np.zeros((70, 200, 3), np.float32)
+    img[:, :110] = rng.uniform(0, 3, size=(70, 110, 3)).astype(np.float32)
+    img[40:, 150:] = 2.5
+    stats = {}
+    p = str(tmp_path / "p.exr")
+    _piz_exr(p, img, {"R": 2, "G": 2, "B": 2}, tile=(128, 64), stats=stats)
+    assert stats["coded_blocks"] >= 1 and stats["max_value"] >= (1 << 14) and stats["longest_code"] > 14
+    back = host.read_exr(p)
+    assert np.array_equal(back[..., :3], img)
+
+
+def test_exr_reader_piz_rejects_damaged_blocks(tmp_path):
+    """Damaged files end in an error or in different pixels, never in a crash."""
+    rng = np.random.default_rng(8)
+    img = _piz_test_image(rng, 64, 90, 3)
+    stats = {}
+    p = str(tmp_path / "p.exr")
+    _piz_exr(p, img, {"R": 1, "G": 2, "B": 1}, stats=stats)
+    assert stats["coded_blocks"] == 2
+    good = open(p, "rb").read()
+    start = good.index(b"screenWindowWidth") + 40                    # past the header: offsets and blocks
+    q = str(tmp_path / "q.exr")
+    errors = 0
+    for k in range(300):
+        bad = bytearray(good)
+        if k % 3 == 0:
+            bad = bad[:int(rng.integers(start, len(good)))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(start, len(bad)))] = int(rng.integers(0, 256))
+        open(q, "wb").write(bytes(bad))
+        try:
+            host.read_exr(q)
+        except (ValueError, OSError, RuntimeError):
+            errors += 1
+    assert errors > 150
+
+
 def test_camera_matrix_matches_python_recipe():
     for t, r in (((0.0, 1.5, -3.0), (-np.pi / 4, 0.0)), ((0.3, 1.2, -2.5), (-0.5, 0.4))):
         assert np.allclose(host.camera_matrix(t, r), camera_matrix(t, r), atol=1e-7)
