@@ -345,12 +345,17 @@ int rth_write_exr(const char *path, int w, int h, int channels, const float *pix
 }
 // Reads an EXR into malloc'ed RGBA float32.
 int rth_read_exr(const char *path, int *w, int *h, float **rgba) {
-    std::vector<float> px;
-    std::string err;
-    if (!host::readEXR(path, *w, *h, px, &err)) return -1;
-    *rgba = (float *)malloc(sizeof(float) * px.size());
-    memcpy(*rgba, px.data(), sizeof(float) * px.size());
-    return 0;
+    try {
+        std::vector<float> px;
+        std::string err;
+        if (!host::readEXR(path, *w, *h, px, &err)) return -1;
+        *rgba = (float *)malloc(sizeof(float) * (px.size() + 1));
+        if (!*rgba) return -1;
+        memcpy(*rgba, px.data(), sizeof(float) * px.size());
+        return 0;
+    } catch (...) {                  // out of memory: no exception may cross the C boundary
+        return -1;
+    }
 }
 void rth_camera_matrix(const double t[3], const double rot[2], float out[16]) { host::cameraMatrix(t, rot, out); }
 

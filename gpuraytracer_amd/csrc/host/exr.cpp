@@ -390,9 +390,11 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
     if (!r.ok || chans.empty() || xmax < xmin || ymax < ymin) return fail("bad header");
     if (compression < 0 || compression > 4) return fail("compression must be NONE, RLE, ZIPS, ZIP or PIZ");
     if (tiled && (tile_w == 0 || tile_h == 0)) return fail("tiled file without a tile description");
-    if (tiled && (tile_mode & 0xFu) != 0) return fail("only tiled files with one level are supported");
-    width = xmax - xmin + 1;
-    height = ymax - ymin + 1;
+    if (tiled && (tile_mode & 0xFu) > 2) return fail("bad level mode in the tile description");
+    const int64_t wide = (int64_t)xmax - xmin + 1, high = (int64_t)ymax - ymin + 1;
+    if (wide > 65536 || high > 65536 || wide * high > ((int64_t)1 << 28)) return fail("data window above 2^28 pixels");
+    width = (int)wide;
+    height = (int)high;
     size_t pixel_bytes = 0;
     for (const Channel &c : chans) {
         if (c.type != 1 && c.type != 2) return fail("channel type must be HALF or FLOAT");
@@ -462,11 +464,14 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
 
     if (tiled) {
         const int nx = (width + (int)tile_w - 1) / (int)tile_w, ny = (height + (int)tile_h - 1) / (int)tile_h;
+        // Files with mip-map or rip-map levels list the tiles of the full-resolution level (0, 0) first in the offset
+        // table; only those are read.
+        if ((size_t)(r.end - r.p) / 8 < (size_t)nx * ny) return fail("truncated offset table");
         std::vector<uint64_t> offsets((size_t)nx * ny);
         for (uint64_t &o : offsets) o = r.u64();
         if (!r.ok) return fail("truncated offset table");
         for (uint64_t off : offsets) {
-            if (off + 20 > data.size()) return fail("bad tile offset");
+            if (off > data.size() || data.size() - off < 20) return fail("bad tile offset");
             Reader br{data.data() + off, data.data() + data.size()};
             const int tx = (int)br.u32(), ty = (int)br.u32();
             const uint32_t lx = br.u32(), ly = br.u32(), size = br.u32();
@@ -480,15 +485,17 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
     }
     const int lines_per_block = compression == 4 ? 32 : compression == 3 ? 16 : 1;
     const int blocks = (height + lines_per_block - 1) / lines_per_block;
+    if ((size_t)(r.end - r.p) / 8 < (size_t)blocks) return fail("truncated offset table");
     std::vector<uint64_t> offsets(blocks);
     for (int i = 0; i < blocks; i++) offsets[i] = r.u64();
     if (!r.ok) return fail("truncated offset table");
     for (int bidx = 0; bidx < blocks; bidx++) {
-        if (offsets[bidx] + 8 > data.size()) return fail("bad block offset");
+        if (offsets[bidx] > data.size() || data.size() - offsets[bidx] < 8) return fail("bad block offset");
         Reader br{data.data() + offsets[bidx], data.data() + data.size()};
-        const int y0 = (int)br.u32() - ymin;
+        const int64_t line = (int64_t)(int32_t)br.u32() - ymin;
         const uint32_t size = br.u32();
-        if (!br.ok || (size_t)(br.end - br.p) < size || y0 < 0 || y0 >= height) return fail("bad block");
+        if (!br.ok || (size_t)(br.end - br.p) < size || line < 0 || line >= height) return fail("bad block");
+        const int y0 = (int)line;
         const char *what = decode_block(br.p, size, 0, y0, width, std::min(lines_per_block, height - y0));
         if (what) return fail(what);
     }

@@ -1,7 +1,7 @@
 // exr.hpp - minimal OpenEXR reader/writer (the reference uses tinyexr's LoadEXR / SaveEXR,
 // Scene.cpp:81,110,504, which is not part of its repository).
 //   write: float32 channels, no compression, 3 (B,G,R) or 4 (A,B,G,R) channels
-//   read : single-part scanline files and tiled files with one level, NONE / RLE / ZIPS / ZIP / PIZ compression,
+//   read : single-part scanline and tiled files (the full-resolution level), NONE / RLE / ZIPS / ZIP / PIZ compression,
 //          HALF or FLOAT channels named R,G,B,(A);
 //          result is RGBA float32 (A = 1 when absent), row 0 = first scanline of the file
 #pragma once

@@ -204,7 +204,7 @@ def test_exr_reader_compressed_half(tmp_path, compression):
     assert np.array_equal(back[..., :3], img.astype(np.float32))
 
 
-def _tiled_exr(path, img_rgb, tile_w, tile_h, compression):
+def _tiled_exr(path, img_rgb, tile_w, tile_h, compression, mip_levels=False):
     """Writes a tiled (one level) FLOAT RGB EXR with Python: version flag 0x200, a `tiles` attribute, one offset per
     tile in row-major tile order, each tile with its coordinates, level (0, 0), size and data (rows of the tile,
     channels B, G, R within a row), compressed like a scanline block."""
@@ -222,7 +222,7 @@ def _tiled_exr(path, img_rgb, tile_w, tile_h, compression):
     hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
     hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
     hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
-    hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tile_w, tile_h, 0)) + b"\0"
+    hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tile_w, tile_h, 1 if mip_levels else 0)) + b"\0"
     tiles = []
     for ty in range((h + tile_h - 1) // tile_h):
         for tx in range((w + tile_w - 1) // tile_w):
@@ -237,6 +237,17 @@ def _tiled_exr(path, img_rgb, tile_w, tile_h, compression):
                 z = _rle(pred.astype(np.uint8).tobytes()) if compression == 1 else zlib.compress(pred.astype(np.uint8).tobytes())
                 data = z if len(z) < len(raw) else raw
             tiles.append(struct.pack("<iiiii", tx, ty, 0, 0, len(data)) + data)
+    if mip_levels:
+        # the smaller levels follow level 0 in the offset table, down to 1 x 1; their pixels do not matter here
+        lw, lh = w, h
+        while lw > 1 or lh > 1:
+            lw, lh = max(1, lw // 2), max(1, lh // 2)
+            lvl = len(bin(w // lw)) - 3
+            for ty in range((lh + tile_h - 1) // tile_h):
+                for tx in range((lw + tile_w - 1) // tile_w):
+                    cw, chh = min(tile_w, lw - tx * tile_w), min(tile_h, lh - ty * tile_h)
+                    raw = bytes(12 * cw * chh)
+                    tiles.append(struct.pack("<iiiii", tx, ty, lvl, lvl, len(raw)) + raw)
     off = len(hdr) + 8 * len(tiles)
     table = b""
     for t in tiles:
@@ -380,6 +391,27 @@ def test_exr_reader_piz_rejects_damaged_blocks(tmp_path):
         except (ValueError, OSError, RuntimeError):
             errors += 1
     assert errors > 150
+
+
+def test_exr_reader_takes_level_0_of_mip_mapped_tiles(tmp_path):
+    rng = np.random.default_rng(9)
+    img = rng.uniform(0, 3, size=(40, 64, 3)).astype(np.float32)
+    p = str(tmp_path / "m.exr")
+    _tiled_exr(p, img, 32, 16, 0, mip_levels=True)
+    back = host.read_exr(p)
+    assert back.shape == (40, 64, 4) and np.array_equal(back[..., :3], img)
+
+
+def test_exr_reader_refuses_absurd_headers(tmp_path):
+    p = str(tmp_path / "a.exr")
+    host.write_exr(p, np.zeros((2, 2, 3), np.float32))
+    raw = bytearray(open(p, "rb").read())
+    at = raw.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    for box in ((0, 0, 2 ** 31 - 1, 2 ** 31 - 1), (-2 ** 31, -2 ** 31, 2 ** 31 - 1, 1), (0, 0, 65535, 65535), (0, 0, 60000, 3)):
+        raw[at:at + 16] = struct.pack("<iiii", *box)
+        open(p, "wb").write(bytes(raw))
+        with pytest.raises(IOError):
+            host.read_exr(p)
 
 
 def test_camera_matrix_matches_python_recipe():
