@@ -873,17 +873,23 @@ def test_host_program_renders_and_writes_exr(oracle_mod, tmp_path):
 
 def test_host_program_loads_material_textures_from_exr(oracle_mod, tmp_path):
     # Scene::loadMaterial of the C++ host (Scene.cpp:206-229 with loadTexture, :75-102): <base>_albedo.exr, _normal.exr
-    # and _arm.exr written by the library's EXR writer go through its reader into the corner of 4096^2 atlas layers
+    # (written by the library's EXR writer) and _arm.exr (HALF channels, PIZ-compressed, written by the tests' Python
+    # writer) go through its reader into the corner of 4096^2 atlas layers
     # (the reference's atlas size) of two materials of a textured height field; the rendered mean image against the checker
     import subprocess
     from conftest import ROOT
     from gpuraytracer_amd import host, synthetic
     base = str(tmp_path / "grid")
     synthetic.write_displaced_grid(base, 24)
-    layers = synthetic.texture_layers(64)
+    from test_host import _piz_exr
+    layers = list(synthetic.texture_layers(64))
+    layers[2] = layers[2].astype(np.float16).astype(np.float32)            # this layer goes through a HALF file
     tex = str(tmp_path / "tex")
-    for suffix, pixels in zip(("albedo", "normal", "arm"), layers):
+    for suffix, pixels in zip(("albedo", "normal"), layers):
         host.write_exr("%s_%s.exr" % (tex, suffix), pixels[..., :3])
+    piz = {}
+    _piz_exr(tex + "_arm.exr", np.ascontiguousarray(layers[2][..., :3]), {"R": 1, "G": 1, "B": 1}, stats=piz)
+    assert piz["coded_blocks"] == 2                                        # PIZ blocks, not blocks stored as they are
     out = str(tmp_path / "final.exr")
     exe = os.path.join(ROOT, "gpuraytracer_amd", "gpuPT")
     res = subprocess.run([exe, base, "64", "48", "3", out, "-", "0=" + tex, "1=" + tex, "2=" + str(tmp_path / "missing")],
