@@ -217,7 +217,7 @@ bool Scene::loadEnvironmentTexture(const std::string &texture_name) {
         std::vector<float> rgb((size_t)ow * oh * 3);
         if (ow && oh) {
             if (rt_prefilter_irradiance(m_ctx, rgb.data(), &ow, &oh) != RT_OK) return false;
-            if (!writeEXR(irr_name, (int)ow, (int)oh, 3, rgb.data(), &err))
+            if (!writeEXR(irr_name, (int)ow, (int)oh, 3, rgb.data(), &err, exrCompressionFor((int)ow, (int)oh)))
                 std::cerr << "Save EXR err: " << err << std::endl;           // Scene.cpp:195-198: reported, not fatal
         }
     }
@@ -278,7 +278,7 @@ bool Scene::exportEXR(const char *name) {
     const float inv = 1.0f / (float)n;
     for (float &v : rgb) v *= inv;
     std::string err;
-    if (!writeEXR(name, m_width, m_height, 3, rgb.data(), &err)) {
+    if (!writeEXR(name, m_width, m_height, 3, rgb.data(), &err, exrCompressionFor(m_width, m_height))) {
         fprintf(stderr, "Save EXR err: %s\n", err.c_str());
         return false;
     }
@@ -342,6 +342,12 @@ void rth_free(void *p) { free(p); }
 int rth_write_exr(const char *path, int w, int h, int channels, const float *pixels) {
     std::string err;
     return host::writeEXR(path, w, h, channels, pixels, &err) ? 0 : -1;
+}
+// compression: 0 none, 3 ZIP, -1 what tinyexr's SaveEXR picks for the size
+int rth_write_exr_compressed(const char *path, int w, int h, int channels, const float *pixels, int compression) {
+    std::string err;
+    if (compression < 0) compression = host::exrCompressionFor(w, h);
+    return host::writeEXR(path, w, h, channels, pixels, &err, compression) ? 0 : -1;
 }
 // Reads an EXR into malloc'ed RGBA float32.
 int rth_read_exr(const char *path, int *w, int *h, float **rgba) {

@@ -291,8 +291,9 @@ const char *piz_decode(const uint8_t *src, size_t size, const std::vector<Channe
 
 }  // namespace
 
-bool writeEXR(const std::string &path, int width, int height, int channels, const float *pixels, std::string *err) {
-    if (width <= 0 || height <= 0 || (channels != 3 && channels != 4) || !pixels) {
+bool writeEXR(const std::string &path, int width, int height, int channels, const float *pixels, std::string *err,
+              int compression) {
+    if (width <= 0 || height <= 0 || (channels != 3 && channels != 4) || !pixels || (compression != 0 && compression != 3)) {
         if (err) *err = "writeEXR: bad arguments";
         return false;
     }
@@ -311,7 +312,7 @@ bool writeEXR(const std::string &path, int width, int height, int channels, cons
         v.push_back(0);
         put_attr(b, "channels", "chlist", v);
     }
-    put_attr(b, "compression", "compression", std::vector<uint8_t>{0});
+    put_attr(b, "compression", "compression", std::vector<uint8_t>{(uint8_t)compression});
     {
         std::vector<uint8_t> v;
         put_u32(v, 0); put_u32(v, 0); put_u32(v, (uint32_t)(width - 1)); put_u32(v, (uint32_t)(height - 1));
@@ -324,25 +325,53 @@ bool writeEXR(const std::string &path, int width, int height, int channels, cons
     { std::vector<uint8_t> v; put_f32(v, 1.0f); put_attr(b, "screenWindowWidth", "float", v); }
     b.push_back(0);          // end of header
 
-    const uint64_t line_bytes = (uint64_t)width * channels * 4;
+    // Blocks of 1 line (no compression) or 16 lines (ZIP); the table of their offsets comes first and is filled in
+    // once the sizes are known.
+    const int lines_per_block = compression == 3 ? 16 : 1;
+    const int blocks = (height + lines_per_block - 1) / lines_per_block;
     const uint64_t table_at = b.size();
-    uint64_t offset = table_at + 8ull * height;
-    for (int y = 0; y < height; y++) { put_u64(b, offset); offset += 8 + line_bytes; }
+    std::vector<uint64_t> offsets(blocks);
+    b.resize(b.size() + 8ull * blocks, 0);
 
     std::ofstream f(path, std::ios::binary);
     if (!f) { if (err) *err = "writeEXR: cannot open " + path; return false; }
     f.write((const char *)b.data(), (std::streamsize)b.size());
-    std::vector<uint8_t> line;
+    uint64_t offset = b.size();
+    std::vector<uint8_t> raw, mixed, packed, head;
     // channel order in the file is alphabetical: (A,) B, G, R; source pixels are RGB(A)
     const int src_of[4] = {3, 2, 1, 0};
-    for (int y = 0; y < height; y++) {
-        line.clear();
-        put_u32(line, (uint32_t)y);
-        put_u32(line, (uint32_t)line_bytes);
-        for (int c = (channels == 4 ? 0 : 1); c < 4; c++)
-            for (int x = 0; x < width; x++) put_f32(line, pixels[((size_t)y * width + x) * channels + src_of[c]]);
-        f.write((const char *)line.data(), (std::streamsize)line.size());
+    for (int k = 0; k < blocks; k++) {
+        const int y0 = k * lines_per_block, y1 = std::min(height, y0 + lines_per_block);
+        raw.clear();
+        for (int y = y0; y < y1; y++)
+            for (int c = (channels == 4 ? 0 : 1); c < 4; c++)
+                for (int x = 0; x < width; x++) put_f32(raw, pixels[((size_t)y * width + x) * channels + src_of[c]]);
+        const std::vector<uint8_t> *data = &raw;
+        if (compression == 3) {
+            // even bytes, then odd bytes; each byte as its difference from the one before (+128); deflate
+            const size_t n = raw.size(), half = (n + 1) / 2;
+            mixed.resize(n);
+            for (size_t i = 0; i < n; i++) mixed[(i & 1) ? half + i / 2 : i / 2] = raw[i];
+            for (size_t i = n - 1; i > 0; i--) mixed[i] = (uint8_t)(mixed[i] - mixed[i - 1] + 128);
+            uLongf got = compressBound((uLong)n);
+            packed.resize(got);
+            if (compress(packed.data(), &got, mixed.data(), (uLong)n) != Z_OK) { if (err) *err = "writeEXR: zlib failed"; return false; }
+            packed.resize(got);
+            if (packed.size() < raw.size()) data = &packed;        // a block that does not shrink is stored as it is
+        }
+        head.clear();
+        put_u32(head, (uint32_t)y0);
+        put_u32(head, (uint32_t)data->size());
+        f.write((const char *)head.data(), (std::streamsize)head.size());
+        f.write((const char *)data->data(), (std::streamsize)data->size());
+        offsets[k] = offset;
+        offset += 8 + data->size();
     }
+    head.clear();
+    for (uint64_t o : offsets) put_u64(head, o);
+    f.seekp((std::streamoff)table_at);
+    f.write((const char *)head.data(), (std::streamsize)head.size());
+    f.flush();
     if (!f) { if (err) *err = "writeEXR: write failed " + path; return false; }
     return true;
 }

@@ -24,6 +24,7 @@ def _lib():
                                            c.POINTER(c.c_uint32)]
         lib.rth_free.argtypes = [c.c_void_p]
         lib.rth_write_exr.argtypes = [c.c_char_p, c.c_int, c.c_int, c.c_int, c.c_void_p]
+        lib.rth_write_exr_compressed.argtypes = [c.c_char_p, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_int]
         lib.rth_read_exr.argtypes = [c.c_char_p, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_void_p)]
         lib.rth_camera_matrix.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
         _LIB = lib
@@ -49,10 +50,11 @@ def load_wavefront(base_path):
     return models, shadings, int(lights.value), materials
 
 
-def write_exr(path, pixels):
+def write_exr(path, pixels, compression=0):
+    """compression: 0 = none, 3 = ZIP, -1 = ZIP unless both sides are under 16 pixels (what the host program writes)."""
     pixels = np.ascontiguousarray(pixels, dtype=np.float32)
     h, w, ch = pixels.shape
-    if _lib().rth_write_exr(path.encode(), w, h, ch, pixels.ctypes.data_as(ctypes.c_void_p)) != 0:
+    if _lib().rth_write_exr_compressed(path.encode(), w, h, ch, pixels.ctypes.data_as(ctypes.c_void_p), compression) != 0:
         raise IOError("cannot write " + path)
 
 

@@ -800,43 +800,7 @@ def test_million_triangles_full_size_forms_agree(gpu_ctx, million_triangles):
     assert sa["rays"] > 1.15 * sa["pixel_samples"] and np.isfinite(a).mean() > 0.999
 
 
-def _read_exr_uncompressed(path):
-    """OpenEXR scanline file without compression, FLOAT channels, read with nothing but struct: returns
-    ({channel name: [h, w] float32}, channel names in file order, header attributes)."""
-    import struct
-    data = open(path, "rb").read()
-    magic, version = struct.unpack_from("<II", data, 0)
-    assert magic == 20000630 and version == 2
-    pos, attrs = 8, {}
-
-    def cstr(at):
-        end = data.index(b"\0", at)
-        return data[at:end].decode(), end + 1
-    while data[pos] != 0:
-        name, pos = cstr(pos)
-        kind, pos = cstr(pos)
-        size = struct.unpack_from("<I", data, pos)[0]
-        attrs[name] = (kind, data[pos + 4:pos + 4 + size])
-        pos += 4 + size
-    pos += 1
-    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
-    xmin, ymin, xmax, ymax = struct.unpack("<iiii", attrs["dataWindow"][1])
-    w, h = xmax - xmin + 1, ymax - ymin + 1
-    names, cl, at = [], attrs["channels"][1], 0
-    while cl[at] != 0:
-        end = cl.index(b"\0", at)
-        names.append(cl[at:end].decode())
-        ptype, _, xs, ys = struct.unpack_from("<IIii", cl, end + 1)
-        assert ptype == 2 and xs == 1 and ys == 1              # FLOAT, no subsampling
-        at = end + 1 + 16
-    offsets = struct.unpack_from("<%dQ" % h, data, pos)
-    planes = {nm: np.empty((h, w), np.float32) for nm in names}
-    for row, off in enumerate(offsets):
-        y, size = struct.unpack_from("<iI", data, off)
-        assert y == ymin + row and size == 4 * w * len(names)
-        for k, nm in enumerate(names):
-            planes[nm][row] = np.frombuffer(data, "<f4", w, off + 8 + 4 * w * k)
-    return planes, names, attrs
+from exr_plain import read_exr_scanlines as _read_exr_scanlines  # noqa: E402
 
 
 def test_host_program_renders_and_writes_exr(oracle_mod, tmp_path):
@@ -855,8 +819,9 @@ def test_host_program_renders_and_writes_exr(oracle_mod, tmp_path):
     res = subprocess.run([exe, base, "64", "48", "4", out], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Scene Loaded" in res.stdout and "samples/s" in res.stdout
-    planes, names, attrs = _read_exr_uncompressed(out)
+    planes, names, attrs = _read_exr_scanlines(out)
     assert names == ["B", "G", "R"]
+    assert attrs["compression"][1] == b"\x03"          # ZIP, what tinyexr's SaveEXR (Scene.cpp:504) picks from 16 pixels on
     scene = host.load_wavefront(base)
     sc = oracle_mod.OracleScene(*scene)
     sc.upload_env(constant_env())
@@ -908,7 +873,7 @@ def test_host_program_loads_material_textures_from_exr(oracle_mod, tmp_path):
     sc.set_has_texture(np.array([1, 1, 0], np.int32))
     want, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 64, 48, 0, 3)
     mean = want * (np.float32(1.0) / np.float32(3.0))
-    planes, names, _ = _read_exr_uncompressed(out)
+    planes, names, _ = _read_exr_scanlines(out)
     got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
     same = (got.view(np.uint32) == mean.view(np.uint32)) | (np.isnan(got) & np.isnan(mean))
     assert same.all(), int((~same).sum())
@@ -963,7 +928,7 @@ def test_several_contexts_in_one_process_add_up(oracle_mod, cubes, tmp_path):
     a, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 40, 24, 0, 3, 2)
     b, _ = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 40, 24, 1, 2, 2)
     mean = (a + b).astype(np.float32) * (np.float32(1.0) / np.float32(5.0))
-    planes, names, _ = _read_exr_uncompressed(out)
+    planes, names, _ = _read_exr_scanlines(out)
     got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
     same = (got.view(np.uint32) == mean.view(np.uint32)) | (np.isnan(got) & np.isnan(mean))
     assert same.all(), int((~same).sum())

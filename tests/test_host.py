@@ -132,6 +132,29 @@ def test_exr_roundtrip(tmp_path):
     assert np.array_equal(host.read_exr(p), rgba)
 
 
+def test_exr_writer_zip(tmp_path):
+    """ZIP blocks of 16 lines, read back by the library's reader and by the tests' own parser (struct + zlib)."""
+    from exr_plain import read_exr_scanlines
+    rng = np.random.default_rng(10)
+    y, x = np.mgrid[0:45, 0:37].astype(np.float32)
+    img = np.stack([x / 8, (x + y) / 16, np.floor(y / 4)], axis=-1).astype(np.float32)
+    img[30:, :] = rng.uniform(0, 1, size=(15, 37, 3)).astype(np.float32)     # noise in the last block
+    p = str(tmp_path / "z.exr")
+    host.write_exr(p, img, compression=3)
+    q = str(tmp_path / "n.exr")
+    host.write_exr(q, img)
+    assert os.path.getsize(p) < os.path.getsize(q)
+    assert np.array_equal(host.read_exr(p)[..., :3], img)
+    planes, names, attrs = read_exr_scanlines(p)
+    assert names == ["B", "G", "R"] and attrs["compression"][1] == b"\x03"
+    assert np.array_equal(np.stack([planes["R"], planes["G"], planes["B"]], axis=-1), img)
+    rgba = rng.uniform(0, 1, size=(17, 5, 4)).astype(np.float32)
+    host.write_exr(p, rgba, compression=-1)                                  # the host program's choice: ZIP from 16 pixels on
+    assert read_exr_scanlines(p)[2]["compression"][1] == b"\x03" and np.array_equal(host.read_exr(p), rgba)
+    host.write_exr(p, rgba[:15], compression=-1)
+    assert read_exr_scanlines(p)[2]["compression"][1] == b"\x00" and np.array_equal(host.read_exr(p), rgba[:15])
+
+
 def _rle(data):
     """OpenEXR's run-length code: count byte n, n < 0: -n literal bytes follow, n >= 0: the next byte n + 1 times."""
     out, i, n = bytearray(), 0, len(data)
