@@ -429,6 +429,13 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
         if (c.type != 1 && c.type != 2) return fail("channel type must be HALF or FLOAT");
         pixel_bytes += c.type == 1 ? 2 : 4;
     }
+    // As tinyexr's LoadEXR (Scene.cpp:81): a file with one channel is a grey image (its value goes to all four
+    // components), any other file needs R, G and B, and A is 1 where the file has none.
+    const bool grey = chans.size() == 1;
+    if (!grey)
+        for (const char *need : {"R", "G", "B"})
+            if (std::none_of(chans.begin(), chans.end(), [&](const Channel &c) { return c.name == need; }))
+                return fail(std::string("no channel ") + need);
     rgba.assign((size_t)width * height * 4, 0.0f);
     for (size_t i = 0; i < (size_t)width * height; i++) rgba[i * 4 + 3] = 1.0f;
 
@@ -478,12 +485,14 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
                 if (c.name == "R") dst = 0; else if (c.name == "G") dst = 1; else if (c.name == "B") dst = 2;
                 else if (c.name == "A") dst = 3;
                 const size_t esz = c.type == 1 ? 2 : 4;
-                if (dst >= 0)
+                if (dst >= 0 || grey)
                     for (int x = 0; x < cols; x++) {
                         float v;
                         if (c.type == 1) { uint16_t h; memcpy(&h, p + x * 2, 2); v = half_to_float(h); }
                         else memcpy(&v, p + (size_t)x * 4, 4);
-                        rgba[((size_t)(y0 + l) * width + (x0 + x)) * 4 + dst] = v;
+                        float *px = &rgba[((size_t)(y0 + l) * width + (x0 + x)) * 4];
+                        if (grey) px[0] = px[1] = px[2] = px[3] = v;
+                        else px[dst] = v;
                     }
                 p += esz * cols;
             }

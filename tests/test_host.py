@@ -437,6 +437,44 @@ def test_exr_reader_refuses_absurd_headers(tmp_path):
             host.read_exr(p)
 
 
+def _plain_exr(path, planes):
+    """An uncompressed FLOAT scanline file of the given channels ({name: [h, w] float32})."""
+    names = sorted(planes)
+    h, w = planes[names[0]].shape
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(val)) + val
+    ch = b"".join(n.encode() + b"\0" + struct.pack("<IBBBBII", 2, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", ch) + attr("compression", "compression", b"\0")
+    hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0")
+    hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    hdr += b"\0"
+    line = 8 + 4 * w * len(names)
+    table = b"".join(struct.pack("<Q", len(hdr) + 8 * h + y * line) for y in range(h))
+    rows = b"".join(struct.pack("<ii", y, line - 8) + b"".join(planes[n][y].astype("<f4").tobytes() for n in names)
+                    for y in range(h))
+    with open(path, "wb") as fh:
+        fh.write(hdr + table + rows)
+
+
+def test_exr_reader_grey_and_missing_channels(tmp_path):
+    """tinyexr's LoadEXR (Scene.cpp:81): one channel of any name fills all four components; otherwise R, G and B
+    must be there, further channels are skipped."""
+    rng = np.random.default_rng(12)
+    v = {n: rng.uniform(0, 1, size=(6, 9)).astype(np.float32) for n in ("R", "G", "B", "Y", "Z")}
+    p = str(tmp_path / "g.exr")
+    _plain_exr(p, {"Y": v["Y"]})
+    assert np.array_equal(host.read_exr(p), np.repeat(v["Y"][..., None], 4, axis=-1))
+    _plain_exr(p, {n: v[n] for n in ("B", "G", "R", "Z")})
+    back = host.read_exr(p)
+    assert np.array_equal(back[..., :3], np.stack([v["R"], v["G"], v["B"]], axis=-1)) and (back[..., 3] == 1).all()
+    _plain_exr(p, {"R": v["R"], "G": v["G"]})
+    with pytest.raises(IOError):
+        host.read_exr(p)
+
+
 def test_camera_matrix_matches_python_recipe():
     for t, r in (((0.0, 1.5, -3.0), (-np.pi / 4, 0.0)), ((0.3, 1.2, -2.5), (-0.5, 0.4))):
         assert np.allclose(host.camera_matrix(t, r), camera_matrix(t, r), atol=1e-7)
