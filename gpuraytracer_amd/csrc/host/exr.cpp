@@ -384,7 +384,8 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
     Reader r{data.data(), data.data() + data.size()};
     if (r.u32() != 20000630u) return fail("not an OpenEXR file");
     const uint32_t version = r.u32();
-    if ((version & 0xFFu) != 2 || (version & 0x1C00u)) return fail("only single-part files without deep data are supported");
+    // flags: 0x200 tiled, 0x400 attribute names of up to 255 characters, 0x800 deep data, 0x1000 several parts
+    if ((version & 0xFFu) != 2 || (version & 0x1800u)) return fail("only single-part files without deep data are supported");
     const bool tiled = (version & 0x200u) != 0;
     std::vector<Channel> chans;
     int compression = -1, xmin = 0, ymin = 0, xmax = -1, ymax = -1;

@@ -473,6 +473,17 @@ def test_exr_reader_grey_and_missing_channels(tmp_path):
     _plain_exr(p, {"R": v["R"], "G": v["G"]})
     with pytest.raises(IOError):
         host.read_exr(p)
+    # version flags: long attribute names are fine, deep data and several parts are refused
+    _plain_exr(p, {"Y": v["Y"]})
+    raw = bytearray(open(p, "rb").read())
+    for flag, ok in ((0x400, True), (0x800, False), (0x1000, False)):
+        raw[4:8] = struct.pack("<I", 2 | flag)
+        open(p, "wb").write(bytes(raw))
+        if ok:
+            assert np.array_equal(host.read_exr(p)[..., 0], v["Y"])
+        else:
+            with pytest.raises(IOError):
+                host.read_exr(p)
 
 
 def test_camera_matrix_matches_python_recipe():
