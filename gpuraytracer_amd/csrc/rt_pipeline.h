@@ -91,17 +91,24 @@ RT_DEV uint32_t lane_index() { return threadIdx.x & 63u; }
 
 constexpr uint32_t N_XCD = 8;
 #ifndef RT_RUNS_PER_XCD
-#define RT_RUNS_PER_XCD 4
+#define RT_RUNS_PER_XCD 16
 #endif
 #ifndef RT_CHUNK_BLOCK
 #define RT_CHUNK_BLOCK 64
 #endif
 #ifndef RT_DYNAMIC_SHARE
-#define RT_DYNAMIC_SHARE 4
+#define RT_DYNAMIC_SHARE 3
+#endif
+#ifndef RT_DYNAMIC_SHARE_LARGE
+#define RT_DYNAMIC_SHARE_LARGE 1
 #endif
 constexpr uint32_t RUNS_PER_XCD = RT_RUNS_PER_XCD, N_RUNS = N_XCD * RUNS_PER_XCD;
-constexpr uint32_t CHUNK_BLOCK = RT_CHUNK_BLOCK;        // consecutive chunks that stay in one run (one tile's samples at 64 per pass)
-constexpr uint32_t DYNAMIC_SHARE = RT_DYNAMIC_SHARE;    // 1/DYNAMIC_SHARE of the rounds is handed out as waves become free
+constexpr uint32_t CHUNK_BLOCK = RT_CHUNK_BLOCK;        // consecutive chunks that stay in one run
+// 1/share of the rounds of the depth-0 kernel is handed out as waves become free (PipeBuffers::dynamic_share): a third
+// for scenes below LARGE_SCENE_TRIANGLES triangles, all of them from there on (measured on MI355X, 128 counters: cubes
+// and _ObiWan 1/3 = 1/2 > 1/1 > 1/4, 1 M triangles 1/1 > 1/2 > 1/3 by 9 %: the longer the searches, the more the
+// chunks differ in cost)
+constexpr uint32_t DYNAMIC_SHARE = RT_DYNAMIC_SHARE, DYNAMIC_SHARE_LARGE = RT_DYNAMIC_SHARE_LARGE;
 // Rounds of a pass.  The queue regions are sized for 1/rounds of the paths a wave may have to hand on (every path of
 // every chunk it renders, if all of them survive).  The launch sequence of a pass is repeated `rounds` times: a wave of
 // the depth-0 kernel stops taking chunks when its region cannot hold another one whole, and carries on in the next
@@ -303,6 +310,7 @@ struct PipeBuffers {
     uint32_t region_cap;
     uint32_t round, rounds;                     // round of the pass these launches belong to, and how many it has (see MAX_ROUNDS)
     uint32_t defer_below;                       // depth-0 chunks with fewer probes than this leave them to the probe stages; 0: never
+    uint32_t dynamic_share;                     // 1/dynamic_share of the depth-0 kernel's rounds is handed out as waves become free
     unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
 };
 
@@ -677,6 +685,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
 #endif
 constexpr uint32_t DEFER_BELOW = RT_DEFER_BELOW;
 constexpr int DEFER_MAX_TRIANGLES = 65536;
+constexpr int LARGE_SCENE_TRIANGLES = 65536;     // from here on the whole depth-0 kernel hands its chunks out dynamically
 
 // Depth 0 in one kernel: camera ray, closest hit, shading, the bounce's light probe and the rest of the bounce.
 // At depth 0 the 64 lanes of a wave are the pixels of one 8x8 tile of one sample, so they all draw the same
@@ -721,14 +730,15 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     // region, gets the same number of chunks from all over the image (the deeper stages work region by region and
     // take as long as their fullest region).  But chunks differ a lot in cost (sky, surfaces, lights), and with fixed
     // shares alone a fifth of the wave slots stood empty while the slowest waves finished (SQ_WAVE_CYCLES against waves
-    // x kernel time).  So the last quarter of the rounds is handed out chunk by chunk as waves become free, through
-    // N_RUNS counters (b.work; one counter sustains about ten million atomic operations a second, they are carried
-    // out beyond the XCDs' own L2s): run x holds the blocks x, x + N_RUNS, ... of CHUNK_BLOCK consecutive chunks of
+    // x kernel time).  So the last third of the rounds (all of them for large scenes: b.dynamic_share) is handed out
+    // chunk by chunk as waves become free, through N_RUNS counters (b.work; one counter sustains about ten million
+    // atomic operations a second, they are carried out beyond the XCDs' own L2s, and the waves wait for them: with 32
+    // counters instead of 128 the kernel took 8 % longer, with 16 a quarter longer): run x holds the blocks x, x + N_RUNS, ... of CHUNK_BLOCK consecutive chunks of
     // that part; a wave starts on a run of its own XCD and goes on to the others when it is used up.  Which wave renders
     // a chunk only decides in which queue region its survivors wait, the image does not depend on it.  The counter
     // value for the next chunk is fetched while the current chunk is rendered.
     const uint32_t n_rounds = (n_chunks + (uint32_t)PIPE_WAVES - 1u) / (uint32_t)PIPE_WAVES;
-    const uint32_t fixed_rounds = RT_DYNAMIC_CHUNKS ? n_rounds - n_rounds / DYNAMIC_SHARE : n_rounds;
+    const uint32_t fixed_rounds = RT_DYNAMIC_CHUNKS ? n_rounds - n_rounds / b.dynamic_share : n_rounds;
     const uint32_t fixed_chunks = fixed_rounds * (uint32_t)PIPE_WAVES;          // may exceed n_chunks when nothing is left
     const uint32_t n_blocks = n_chunks > fixed_chunks ? (n_chunks - fixed_chunks + CHUNK_BLOCK - 1u) / CHUNK_BLOCK : 0u;
     const uint32_t home = (blockIdx.x % N_XCD) * RUNS_PER_XCD + (blockIdx.x / N_XCD) % RUNS_PER_XCD;
@@ -1498,6 +1508,7 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
         buf.round = round;
         buf.rounds = rounds;
         buf.defer_below = (CFG::BVH && sc.count < DEFER_MAX_TRIANGLES) ? DEFER_BELOW : 0u;
+        buf.dynamic_share = (CFG::BVH && sc.count >= LARGE_SCENE_TRIANGLES) ? DYNAMIC_SHARE_LARGE : DYNAMIC_SHARE;
         PIPE_TRY(stamp(round == 0 ? 3 : 4));
         if (round == 0) hipLaunchKernelGGL((k_first<CFG, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
         else hipLaunchKernelGGL((k_first<CFG, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
