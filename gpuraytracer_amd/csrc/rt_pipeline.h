@@ -733,10 +733,11 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     // x kernel time).  So the last third of the rounds (all of them for large scenes: b.dynamic_share) is handed out
     // chunk by chunk as waves become free, through N_RUNS counters (b.work; one counter sustains about ten million
     // atomic operations a second, they are carried out beyond the XCDs' own L2s, and the waves wait for them: with 32
-    // counters instead of 128 the kernel took 8 % longer, with 16 a quarter longer): run x holds the blocks x, x + N_RUNS, ... of CHUNK_BLOCK consecutive chunks of
-    // that part; a wave starts on a run of its own XCD and goes on to the others when it is used up.  Which wave renders
-    // a chunk only decides in which queue region its survivors wait, the image does not depend on it.  The counter
-    // value for the next chunk is fetched while the current chunk is rendered.
+    // counters instead of 128 the kernel takes 8 % longer, with 16 counters 37 %): run x holds the blocks x,
+    // x + N_RUNS, ... of CHUNK_BLOCK consecutive chunks of that part; a wave starts on a run of its own XCD and goes on
+    // to the others when it is used up.  Which wave renders a chunk only decides in which queue region its survivors
+    // wait, the image does not depend on it.  The counter value for the next chunk is fetched while the current chunk
+    // is rendered.
     const uint32_t n_rounds = (n_chunks + (uint32_t)PIPE_WAVES - 1u) / (uint32_t)PIPE_WAVES;
     const uint32_t fixed_rounds = RT_DYNAMIC_CHUNKS ? n_rounds - n_rounds / b.dynamic_share : n_rounds;
     const uint32_t fixed_chunks = fixed_rounds * (uint32_t)PIPE_WAVES;          // may exceed n_chunks when nothing is left
