@@ -17,6 +17,7 @@ EXPORTS = [
     "rt_set_atlas_size", "rt_upload_atlas_layer", "rt_set_has_texture", "rt_upload_env", "rt_prefilter_irradiance", "rt_resize",
     "rt_set_sum_buffer", "rt_set_frame", "rt_trace", "rt_read_sum", "rt_read_sum_static", "rt_closest_hit_batch",
     "rt_closest_hit_batch_device", "rt_read_srgb8", "rt_get_stats", "rt_reset_stats", "rt_set_option", "rt_accumulate_from",
+    "rt_select_target", "rt_clear",
 ]
 
 
@@ -71,6 +72,8 @@ def load_library():
     lib.rt_prefilter_irradiance.argtypes = [vp, vp, c.POINTER(c.c_uint32), c.POINTER(c.c_uint32)]
     lib.rt_resize.argtypes = [vp, c.c_uint32, c.c_uint32]
     lib.rt_set_sum_buffer.argtypes = [vp, vp]
+    lib.rt_select_target.argtypes = [vp, c.c_int]
+    lib.rt_clear.argtypes = [vp]
     lib.rt_set_frame.argtypes = [vp, vp, c.c_uint32, c.c_int32, c.c_float]
     lib.rt_trace.argtypes = [vp, c.c_uint32, c.c_uint32, c.c_uint32]
     lib.rt_read_sum.argtypes = [vp, vp, c.POINTER(c.c_uint64)]
@@ -104,6 +107,8 @@ class Context:
             raise GpuRtError(rc, "rt_create(device=%d) failed" % device)
         self.h = h
         self.width = self.height = 0
+        self._parked_size = (0, 0)
+        self.target = 0
 
     def _check(self, rc):
         if rc != 0:
@@ -174,6 +179,17 @@ class Context:
     def resize(self, width, height):
         self._check(self.lib.rt_resize(self.h, width, height))
         self.width, self.height = width, height
+
+    def select_target(self, target):
+        """0 = the still image, 1 = the low-resolution preview (Scene::prepare's choice of render target)."""
+        self._check(self.lib.rt_select_target(self.h, int(target)))
+        if int(target) != self.target:
+            (self.width, self.height), self._parked_size = self._parked_size, (self.width, self.height)
+            self.target = int(target)
+
+    def clear(self):
+        """The selected target starts over (what SAMPLE 0 does to the reference's running mean)."""
+        self._check(self.lib.rt_clear(self.h))
 
     def set_sum_buffer(self, device_ptr):
         self._check(self.lib.rt_set_sum_buffer(self.h, ctypes.c_void_p(device_ptr)))

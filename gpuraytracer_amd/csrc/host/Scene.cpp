@@ -229,30 +229,42 @@ bool Scene::setEnvironment(uint32_t w, uint32_t h, const float *rgba) {
     return rt_upload_env(m_ctx, w, h, rgba) == RT_OK;
 }
 
+// Scene.cpp:397-421 makes two targets: renderTarget at the window's size and renderTargetLow for the moving preview.
+// Here the preview target gets the size prepare() traces at in moving mode, 240 rows (the reference allocates 180 rows
+// and dispatches 240: OpenGL drops the stores beyond its texture).
 bool Scene::adaptResolution(int width, int height) {
-    if (!m_ctx) return false;
+    if (!m_ctx || width <= 0 || height <= 0) return false;
     if (width == m_width && height == m_height) return true;
-    if (rt_resize(m_ctx, (uint32_t)width, (uint32_t)height) != RT_OK) return false;
-    m_width = width;
-    m_height = height;
+    const int low_w = (int)(240.0 / height * width), low_h = 240;
+    if (rt_select_target(m_ctx, 1) != RT_OK || rt_resize(m_ctx, (uint32_t)(low_w > 0 ? low_w : 1), (uint32_t)low_h) != RT_OK) return false;
+    if (rt_select_target(m_ctx, 0) != RT_OK || rt_resize(m_ctx, (uint32_t)width, (uint32_t)height) != RT_OK) return false;
+    m_moving = false;
+    m_width = width; m_height = height;
+    m_low_width = low_w > 0 ? low_w : 1; m_low_height = low_h;
     return true;
 }
 
 bool Scene::prepare(int &width, int &height, bool moving, const float camera[16], uint32_t clock) {
     if (!m_ctx) return false;
-    if (moving) {                                     // Scene.cpp:449-457
-        width = (int)(240.0 / height * width);
-        height = 240;
-    }
-    if (m_first_prepare || width != m_width || height != m_height) {
+    if (m_first_prepare || (!moving && (width != m_width || height != m_height))) {
         if (!adaptResolution(width, height)) return false;
         m_first_prepare = false;
     }
+    if (moving) {                                     // Scene.cpp:449-457: the other target, its size, RECURSION 3
+        width = (int)(240.0 / height * width);
+        height = 240;
+    }
+    // which target the next traceScene / export calls work on (glBindImageTexture(0, ...) at Scene.cpp:450, :459); the
+    // one left behind keeps its sums and sample count
+    if (rt_select_target(m_ctx, moving ? 1 : 0) != RT_OK) return false;
+    m_moving = moving;
     return rt_set_frame(m_ctx, camera, clock, moving ? recursion_moving : recursion_still, exposure) == RT_OK;
 }
 
 bool Scene::traceScene(uint32_t width, uint32_t height, uint32_t sample) {
-    if ((int)width != m_width || (int)height != m_height) { m_error = "traceScene: size differs from prepare()"; return false; }
+    if ((int)width != targetWidth() || (int)height != targetHeight()) { m_error = "traceScene: size differs from prepare()"; return false; }
+    // SAMPLE 0 starts an image over: the reference's running mean multiplies what is there by 0 / 1 (raytracer.glsl:611-613)
+    if (sample == 0 && rt_clear(m_ctx) != RT_OK) return false;
     return rt_trace(m_ctx, sample, 1, 1) == RT_OK;
 }
 
@@ -272,6 +284,7 @@ bool Scene::addSumsOf(Scene &other) {
 
 bool Scene::exportEXR(const char *name) {
     if (!m_ctx || m_width == 0) return false;
+    const int m_width = targetWidth(), m_height = targetHeight();      // of the target prepare() selected
     std::vector<float> rgb((size_t)m_width * m_height * 3);
     uint64_t n = 0;
     if (rt_read_sum(m_ctx, rgb.data(), &n) != RT_OK || n == 0) return false;
@@ -287,6 +300,7 @@ bool Scene::exportEXR(const char *name) {
 
 bool Scene::exportPNG8(const char *name) {
     if (!m_ctx || m_width == 0) return false;
+    const int m_width = targetWidth(), m_height = targetHeight();
     std::vector<uint8_t> rgb((size_t)m_width * m_height * 3);
     if (rt_read_srgb8(m_ctx, rgb.data()) != RT_OK) return false;
     std::ofstream f(name, std::ios::binary);

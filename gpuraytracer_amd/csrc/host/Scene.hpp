@@ -42,9 +42,10 @@ public:
     bool loadMaterial(const std::string &name, uint32_t material_id);   // Scene.cpp:206-229: <name>_albedo/_normal/_arm.exr
     bool loadEnvironmentTexture(const std::string &texture_name);       // Scene.cpp:104-160
     bool setEnvironment(uint32_t w, uint32_t h, const float *rgba);     // environment from memory (no file)
-    bool adaptResolution(int width, int height);                        // Scene.cpp:397-421
-    // CAMERA is column-major (glm::fmat4); moving = the reference's low-resolution preview mode
-    // (RECURSION 3 instead of 6, Scene.cpp:449-463).
+    bool adaptResolution(int width, int height);                        // Scene.cpp:397-421: the still target and the preview target
+    // CAMERA is column-major (glm::fmat4); moving = the reference's low-resolution preview mode (its own target of 240
+    // rows, RECURSION 3 instead of 6, Scene.cpp:449-463): width and height come back as that target's size, and the
+    // still target keeps what it has accumulated.
     bool prepare(int &width, int &height, bool moving, const float camera[16], uint32_t clock);   // Scene.cpp:435-464
     bool traceScene(uint32_t width, uint32_t height, uint32_t sample);  // Scene.cpp:423-433
     bool traceSamples(uint32_t sample_begin, uint32_t sample_count, uint32_t stride = 1);
@@ -76,7 +77,11 @@ private:
     rt_context *m_ctx = nullptr;
     bool m_initialized = false;
     bool m_first_prepare = true;
-    int m_width = 0, m_height = 0;
+    int m_width = 0, m_height = 0;                  // still target
+    int m_low_width = 0, m_low_height = 0;          // preview target
+    bool m_moving = false;                          // which one prepare() selected
+    int targetWidth() const { return m_moving ? m_low_width : m_width; }
+    int targetHeight() const { return m_moving ? m_low_height : m_height; }
     uint32_t m_atlas_size = 4096;
     std::string m_error;
 };

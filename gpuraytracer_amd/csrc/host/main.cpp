@@ -2,12 +2,17 @@
 // scene, renders `spp` samples per pixel with the fixed camera of the reference's start-up state and
 // writes the mean image as OpenEXR, printing samples per second like finalRender (RayTracer.cpp:29-53).
 //
-//   gpuPT [--devices=0,1,...] <model base path> <width> <height> [spp=64] [out.exr=final.exr] [env.exr|-]
+//   gpuPT [--devices=0,1,...] [--preview=K] <model base path> <width> <height> [spp=64] [out.exr=final.exr] [env.exr|-]
 //         [<material id>=<texture base> ...]
 //
 // Without an environment file (or with "-") a constant (0.5, 0.7, 1.0) sky is used (the reference's environment
 // textures are not part of its repository).  "<id>=<base>" loads <base>_albedo.exr, <base>_normal.exr and
 // <base>_arm.exr into the atlas layers of material <id>, as the loadMaterial calls of RayTracer.cpp:161-162 do.
+//
+// --preview=K (one GPU) plays the reference's interactive sequence (RayTracer.cpp:122-143): the still image is traced
+// sample by sample, after half of its samples the camera "moves" for K frames (prepare(moving = true): the low-resolution
+// target, RECURSION 3, a camera one step further back, SAMPLE 0 .. K-1), the preview is written to <out>.preview.exr, and
+// the still image then carries on from where it was.
 //
 // --devices names the GPUs to render on (the same ordinal may appear more than once).  The scene is replicated,
 // GPU r of N renders SAMPLE = r, r + N, r + 2N, ... (all GPUs are driven from this one thread: tracing only enqueues
@@ -25,6 +30,7 @@
 int main(int argc, char *argv[]) {
     std::vector<int> devices;
     std::vector<std::string> args;
+    int preview_frames = 0;
     for (int k = 1; k < argc; k++) {
         const std::string a(argv[k]);
         if (a.rfind("--devices=", 0) == 0) {
@@ -36,6 +42,8 @@ int main(int argc, char *argv[]) {
                 if (comma == std::string::npos) break;
                 pos = comma + 1;
             }
+        } else if (a.rfind("--preview=", 0) == 0) {
+            preview_frames = atoi(a.c_str() + 10);
         } else {
             args.push_back(a);
         }
@@ -86,6 +94,24 @@ int main(int argc, char *argv[]) {
     }
 
     const auto t0 = std::chrono::steady_clock::now();
+    if (preview_frames > 0 && n_dev == 1) {
+        host::Scene &scene = *scenes[0];
+        uint32_t sample = 0;
+        for (; sample < spp / 2; sample++)
+            if (!scene.traceScene((uint32_t)width, (uint32_t)height, sample)) { fprintf(stderr, "%s\n", scene.lastError()); return 1; }
+        const double moved[3] = {0.0, 1.5, -3.5};
+        float camera_moved[16];
+        host::cameraMatrix(moved, rot, camera_moved);
+        int low_w = width, low_h = height;
+        if (!scene.prepare(low_w, low_h, true, camera_moved, 95834783u)) { fprintf(stderr, "%s\n", scene.lastError()); return 1; }
+        for (int k = 0; k < preview_frames; k++)
+            if (!scene.traceScene((uint32_t)low_w, (uint32_t)low_h, (uint32_t)k)) { fprintf(stderr, "%s\n", scene.lastError()); return 1; }
+        if (!scene.exportEXR((out + ".preview.exr").c_str())) { fprintf(stderr, "%s\n", scene.lastError()); return 1; }
+        std::cout << "preview " << low_w << 'x' << low_h << ", " << preview_frames << " frames" << '\n';
+        if (!scene.prepare(width, height, false, camera, 95834783u)) { fprintf(stderr, "%s\n", scene.lastError()); return 1; }
+        for (; sample < spp; sample++)
+            if (!scene.traceScene((uint32_t)width, (uint32_t)height, sample)) { fprintf(stderr, "%s\n", scene.lastError()); return 1; }
+    } else
     for (uint32_t r = 0; r < n_dev; r++) {
         const uint32_t count = spp > r ? (spp - r + n_dev - 1) / n_dev : 0u;       // samples r, r + N, ... below spp
         if (count && !scenes[r]->traceSamples(r, count, n_dev)) { fprintf(stderr, "%s\n", scenes[r]->lastError()); return 1; }

@@ -50,10 +50,17 @@ struct rt_context {
     DevBvh bvh, light_bvh;
     int accel = -1;            // -1 auto (hierarchy from ACCEL_AUTO_MIN triangles on), 0 brute force, 1 hierarchy
 
-    // target
+    // the selected target (rt_select_target); the other one waits in `parked`
     uint32_t width = 0, height = 0;
     float4 *d_sum_own = nullptr, *d_sum = nullptr;
     uint64_t n_samples = 0;
+    struct Target {
+        uint32_t width = 0, height = 0;
+        float4 *d_sum_own = nullptr, *d_sum = nullptr;
+        uint64_t n_samples = 0;
+    };
+    Target parked;
+    int target = 0;            // 0 = the still image, 1 = the low-resolution preview
 
     // frame
     DFrame frame;
@@ -76,6 +83,7 @@ struct rt_context {
     // stats
     DStats *d_stats = nullptr;
     rt_stats host_stats;
+    uint64_t staged_paths_expected = 0;   // camera paths the staged passes since the last reset were asked to render
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     Pipeline pipe;
@@ -184,12 +192,6 @@ hipError_t upload_bvh(const rt_triangle_model *tris, uint32_t count, rt_context:
     return e;
 }
 
-uint32_t pcg_hash_host(uint32_t k) {
-    const uint32_t state = k * 747796405u + 2891336453u;
-    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
-    return (word >> 22u) ^ word;
-}
-
 // light_seed of a sample = CLOCK hashed SAMPLE times (raytracer.glsl:595-598); the chain is
 // continued from the last position when samples ascend.
 uint32_t light_seed_for(rt_context *ctx, uint32_t sample) {
@@ -199,7 +201,7 @@ uint32_t light_seed_for(rt_context *ctx, uint32_t sample) {
         ctx->chain_valid = true;
     }
     while (ctx->chain_pos < sample) {
-        ctx->chain_val = pcg_hash_host(ctx->chain_val);
+        ctx->chain_val = pcg_hash_on_host(ctx->chain_val);
         ctx->chain_pos++;
     }
     return ctx->chain_val;
@@ -324,6 +326,7 @@ int rt_destroy(rt_context *ctx) {
     ctx->pipe.release();
     if (ctx->d_env) (void)hipFree(ctx->d_env);
     if (ctx->d_sum_own) (void)hipFree(ctx->d_sum_own);
+    if (ctx->parked.d_sum_own) (void)hipFree(ctx->parked.d_sum_own);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -524,6 +527,33 @@ int rt_resize(rt_context *ctx, uint32_t width, uint32_t height) {
     ctx->height = height;
     ctx->n_samples = 0;
     memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
+    ctx->staged_paths_expected = 0;
+    return RT_OK;
+}
+
+int rt_select_target(rt_context *ctx, int target) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (target != 0 && target != 1) return fail(ctx, RT_ERR_INVALID, "rt_select_target: target %d is neither 0 (still) nor 1 (preview)", target);
+    if (target == ctx->target) return RT_OK;
+    // work already enqueued keeps the buffer it was launched with; nothing has to be waited for
+    rt_context::Target now;
+    now.width = ctx->width; now.height = ctx->height;
+    now.d_sum_own = ctx->d_sum_own; now.d_sum = ctx->d_sum;
+    now.n_samples = ctx->n_samples;
+    ctx->width = ctx->parked.width; ctx->height = ctx->parked.height;
+    ctx->d_sum_own = ctx->parked.d_sum_own; ctx->d_sum = ctx->parked.d_sum;
+    ctx->n_samples = ctx->parked.n_samples;
+    ctx->parked = now;
+    ctx->target = target;
+    return RT_OK;
+}
+
+int rt_clear(rt_context *ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (ctx->width == 0 || !ctx->d_sum) return fail(ctx, RT_ERR_STATE, "rt_clear: no target (rt_resize)");
+    if (bind_device(ctx)) return RT_ERR_DEVICE;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_sum, 0, sizeof(float4) * (size_t)ctx->width * ctx->height, ctx->stream));
+    ctx->n_samples = 0;
     return RT_OK;
 }
 
@@ -626,8 +656,6 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s", msg ? msg : "queues",
                             hipGetErrorString(e));
-        } else if (ctx->pipe.cap_paths / pps < chunk_max) {
-            chunk_max = (uint32_t)(ctx->pipe.cap_paths / pps);
         }
     }
 
@@ -663,6 +691,7 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
         }
         done += n;
     }
+    if (ctx->pipeline != 0) ctx->staged_paths_expected += (uint64_t)ctx->width * ctx->height * sample_count;
     ctx->n_samples += sample_count;
     return RT_OK;
 }
@@ -794,9 +823,11 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof(ds), hipMemcpyDeviceToHost));
     unsigned long long ws[WSTAT_SLOTS];
     HIP_TRY(ctx, ctx->pipe.read_wstats(ws));
-    bool lost = false;
-    HIP_TRY(ctx, ctx->pipe.read_lost(&lost));
-    if (lost) return fail(ctx, RT_ERR_DEVICE, "rt_get_stats: a pass ended with camera paths not rendered (queue_rounds)");
+    // the rounds of a pass get through all its chunks by the sizing of the queue regions; were that ever wrong, camera
+    // paths would be missing from the count
+    if (ws[WSTAT_PATHS] != ctx->staged_paths_expected)
+        return fail(ctx, RT_ERR_DEVICE, "rt_get_stats: %llu of %llu camera paths were rendered (queue_rounds)",
+                    (unsigned long long)ws[WSTAT_PATHS], (unsigned long long)ctx->staged_paths_expected);
     ds.pixel_samples += ws[WSTAT_PATHS];
     ds.rays += ws[WSTAT_RAYS];
     ds.shadow_probes += ws[WSTAT_SHADOW];
@@ -831,6 +862,7 @@ int rt_reset_stats(rt_context *ctx) {
     HIP_TRY(ctx, ctx->pipe.reset_wstats(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
+    ctx->staged_paths_expected = 0;
     rt_stats discarded;
     memset(&discarded, 0, sizeof(discarded));
     HIP_TRY(ctx, ctx->pipe.collect_times(&discarded));

@@ -19,7 +19,8 @@ struct DStats {
 // The per-pass table travels by value in the kernel arguments (2 KB), so a pass needs no host-to-device copy and no
 // staging buffer: the SAMPLE of slot k of the batch is first_sample + k * stride, and light_seed[k] is its light seed =
 // CLOCK hashed SAMPLE times (raytracer.glsl:595-598).  The coin of a bounce (raytracer.glsl:553: unitFloat(light_seed)
-// < 0.5, drawn once per bounce from a stream all pixels of a sample share) is recomputed from light_seed where it is needed.
+// < 0.5, drawn once per bounce from a stream all pixels of a sample share) is drawn from light_seed where it is needed; the
+// staged kernels of deeper bounces get a copy of the table whose seeds the host has advanced to their depth.
 #ifndef RT_MAX_BATCH
 #define RT_MAX_BATCH 512
 #endif
@@ -29,11 +30,6 @@ struct PassTables {
     uint32_t light_seed[MAX_BATCH];
 };
 RT_DEV uint32_t sample_of_slot(const PassTables &tab, uint32_t k) { return tab.first_sample + k * tab.stride; }
-// light_seed after the draws of `depth` earlier bounces
-RT_DEV uint32_t light_seed_at(uint32_t light_seed, int depth) {
-    for (int d = 0; d < depth; d++) light_seed = pcg_hash(light_seed);
-    return light_seed;
-}
 // Draws the bounce's coin: true = sampleLight, false = sampleLightGlossy.
 RT_DEV bool draw_coin(uint32_t &light_seed) { return unit_float(light_seed) < 0.5f; }
 

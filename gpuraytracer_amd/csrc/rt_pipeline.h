@@ -302,8 +302,7 @@ struct PipeBuffers {
     uint32_t *n_ext[2], *n_shadow, *n_glossy;   // fill count of each region
     uint32_t *work;                             // [N_RUNS] chunks of the depth-0 kernel handed out so far, per part of the target;
                                                 // then [MAX_ROUNDS + 1] `more` flags: more[r] != 0 = round r of the pass left chunks undone
-    uint32_t *resume;                           // [PIPE_WAVES] the fixed share of each wave: how far the rounds so far have come;
-                                                // then one word that is set if the last round of a pass ever left chunks undone
+    uint32_t *resume;                           // [PIPE_WAVES] the fixed share of each wave: how far the rounds so far have come
     uint32_t *claim;                            // [3][PIPE_WAVES] pool blocks of each region handed out so far, for the extend, the shadow
                                                 // and the glossy stage; each zero when its stage starts
     unsigned long long *pool_map;               // [PIPE_WAVES / 64] one bit per region whose pool may have blocks left (k_extend)
@@ -464,6 +463,7 @@ RT_DEV void store_probe_rec(const PipeBuffers &b, size_t i, const PathState &ps,
 // Shading of one path after its closest hit is known (raytracer.glsl:452-556): adds the sky on a
 // miss, otherwise runs shade_pre and hands the path to the shadow queue, the glossy queue or (no
 // probe needed) through the rest of the bounce to the next extend queue.  Called by whole waves.
+// `tab` holds the light seeds as they stand at this depth (the host advances its copy of the table from launch to launch).
 RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffers &b, int depth, int q_in, const PassTables &tab,
                             uint32_t paths_per_sample, int max_depth, bool live, uint32_t id, PathState &ps, uint32_t kept_flags,
                             int hit, float hu, float hv, float ht, RouteFill &fill) {
@@ -474,7 +474,7 @@ RT_DEV void shade_and_route(const DScene &sc, const DFrame &fr, const PipeBuffer
         if (hit < 0) {
             ps.energy = ps.energy + sky_color(sc, fr, ps.d) * ps.path;             // :452-456
         } else {
-            uint32_t ls = light_seed_at(tab.light_seed[id / paths_per_sample], depth);
+            uint32_t ls = tab.light_seed[id / paths_per_sample];
             const bool coin_diffuse = draw_coin(ls);
             shade_pre(sc, fr, ps, hit, hu, hv, ht, coin_diffuse, bn);
             if (bn.kind == PROBE_NONE) {
@@ -746,7 +746,10 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     const uint32_t first = first_chunk_of_wave();
     uint32_t round = LATER ? b.resume[wave] : 0u, part = 0, run_x = home, run_count = 0, ahead = 0;
     bool have_ahead = false;
-    bool stalled = false;      // this wave's region is full and chunks may be left: the pass needs another round
+    // this wave's region is full while chunks may be left (other waves may still take them): the pass gets another round.
+    // In the last round the regions that have room left can hold everything that is left (region_cap_for), so a wave that
+    // stalls there loses nothing; rt_get_stats checks that by counting the camera paths that were rendered.
+    bool stalled = false;
     auto enter_part = [&]() {
         run_x = run_of_part(home, part);
         run_count = n_blocks > run_x ? ((n_blocks - run_x + N_RUNS - 1u) / N_RUNS) * CHUNK_BLOCK : 0u;
@@ -889,7 +892,6 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         b.n_ext[1][wave] = fill_next;
         b.resume[wave] = round;
         if (stalled) more_flags(b.work)[b.round] = 1u;
-        if (stalled && b.round + 1u == b.rounds) b.resume[PIPE_WAVES] = 1u;      // cannot happen by the sizing of the regions
     }
     wstat_add(b, WSTAT_PATHS, n_paths);
     wstat_add(b, WSTAT_RAYS, n_paths);
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, RT_MIN_WAVES) void k_tail(DScene sc,
         ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
         if (kept_flags & KEPT_DIFF) { const float4 k = b.kd[id]; ps.kept_diff = mk3(k.x, k.y, k.z); }
         if (kept_flags & KEPT_SPEC) { const float4 k = b.ks[id]; ps.kept_spec = mk3(k.x, k.y, k.z); }
-        light_seed = light_seed_at(tab.light_seed[id / paths_per_sample], depth0);
+        light_seed = tab.light_seed[id / paths_per_sample];       // as it stands at depth0: the host has advanced the table
     };
     // one bounce of every lane with `alive`, each at its own `depth`
     auto bounce = [&](int depth) {
@@ -1301,6 +1303,13 @@ struct PassForm {
     int staged_depths;   // bounces after the first that run as staged kernels before the tail kernel takes the rest; < 0: all
 };
 
+// pcgHash (raytracer.glsl:89-94) on the host, for the tables of a pass.
+inline uint32_t pcg_hash_on_host(uint32_t k) {
+    const uint32_t state = k * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
 // Host side of the pipeline: buffers sized for one batch, and the launch sequence.
 struct Pipeline {
     PipeBuffers buf = {};
@@ -1368,7 +1377,7 @@ struct Pipeline {
             PIPE_ALLOC(buf.n_shadow, sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.n_glossy, sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.work, sizeof(uint32_t) * (N_RUNS + MAX_ROUNDS + 1));
-            PIPE_ALLOC(buf.resume, sizeof(uint32_t) * (PIPE_WAVES + 1));
+            PIPE_ALLOC(buf.resume, sizeof(uint32_t) * PIPE_WAVES);
             PIPE_ALLOC(buf.claim, sizeof(uint32_t) * 3 * PIPE_WAVES);
             *what = "memset claim";
             e = hipMemset(buf.claim, 0, sizeof(uint32_t) * 3 * PIPE_WAVES);
@@ -1378,7 +1387,7 @@ struct Pipeline {
             e = hipMemset(buf.pool_map, 0, sizeof(unsigned long long) * (PIPE_WAVES / 64));
             if (e != hipSuccess) goto failed;
             *what = "memset resume";
-            e = hipMemset(buf.resume, 0, sizeof(uint32_t) * (PIPE_WAVES + 1));
+            e = hipMemset(buf.resume, 0, sizeof(uint32_t) * PIPE_WAVES);
             if (e != hipSuccess) goto failed;
         }
         if (paths > cap_paths || (need_h0 && !have_h0) || want_rounds != rounds) {
@@ -1455,15 +1464,6 @@ struct Pipeline {
         for (size_t i = 0; i < h.size(); i++) out[i % WSTAT_SLOTS] += h[i];
         return hipSuccess;
     }
-    // True if a pass ever ended with chunks undone (the sizing of the regions rules it out; checked with the statistics).
-    hipError_t read_lost(bool *lost) {
-        *lost = false;
-        if (!buf.resume) return hipSuccess;
-        uint32_t v = 0;
-        const hipError_t e = hipMemcpy(&v, buf.resume + PIPE_WAVES, sizeof(v), hipMemcpyDeviceToHost);
-        *lost = v != 0;
-        return e;
-    }
     hipError_t reset_wstats(hipStream_t stream) {
         if (!buf.wstats) return hipSuccess;
         return hipMemsetAsync(buf.wstats, 0, sizeof(unsigned long long) * WSTAT_SLOTS * PIPE_WAVES, stream);
@@ -1504,6 +1504,12 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
     // depth 0 runs its probes in place (k_first): queue 0 is never read and the first queue is 1
     PIPE_TRY(hipMemsetAsync(buf.work, 0, sizeof(uint32_t) * (N_RUNS + MAX_ROUNDS + 1), stream));
     const int staged_end = form.staged_depths < 0 ? max_depth : (1 + form.staged_depths < max_depth ? 1 + form.staged_depths : max_depth);
+    // light seeds of the pass's samples as they stand at each staged depth and where the tail kernel starts: every bounce
+    // draws once from the stream all pixels of a sample share (raytracer.glsl:553), so the table a launch gets is the
+    // one before hashed once more, and no kernel has to redo the draws of the earlier bounces
+    std::vector<PassTables> tab_at((size_t)staged_end + 1, tab);
+    for (int depth = 1; depth <= staged_end; depth++)
+        for (uint32_t k = 0; k < tab.n; k++) tab_at[depth].light_seed[k] = pcg_hash_on_host(tab_at[depth - 1].light_seed[k]);
     for (uint32_t round = 0; round < rounds; round++) {
         // launches of the rounds after the first are timed with the others but not counted as launches (most return at once)
         buf.round = round;
@@ -1530,9 +1536,9 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
                 hipLaunchKernelGGL(k_extend_refill<CFG>, grid, block, 0, stream, sc, bvh, buf, q_in);
                 PIPE_TRY(hipGetLastError());
                 PIPE_TRY(stamp(2));
-                hipLaunchKernelGGL(k_shade, grid, block, 0, stream, sc, fr, buf, depth, q_in, tab, pps, max_depth);
+                hipLaunchKernelGGL(k_shade, grid, block, 0, stream, sc, fr, buf, depth, q_in, tab_at[depth], pps, max_depth);
             } else {
-                hipLaunchKernelGGL(k_extend<CFG>, grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, tab, pps, max_depth);
+                hipLaunchKernelGGL(k_extend<CFG>, grid, block, 0, stream, sc, bvh, fr, buf, depth, q_in, tab_at[depth], pps, max_depth);
             }
             PIPE_TRY(hipGetLastError());
             PIPE_TRY(stamp(round == 0 ? 1 : 6));
@@ -1545,7 +1551,7 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
         }
         if (staged_end < max_depth) {
             PIPE_TRY(stamp(round == 0 ? 0 : 5));
-            hipLaunchKernelGGL(k_tail<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, staged_end, q_in, tab, pps, max_depth);
+            hipLaunchKernelGGL(k_tail<CFG>, grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, staged_end, q_in, tab_at[staged_end], pps, max_depth);
             PIPE_TRY(hipGetLastError());
             PIPE_TRY(stamp(-1));
         }

@@ -138,6 +138,19 @@ int rt_prefilter_irradiance(rt_context *ctx, float *rgb, uint32_t *out_w, uint32
  * several GPUs add. */
 int rt_resize(rt_context *ctx, uint32_t width, uint32_t height);
 
+/* Scene::prepare's glBindImageTexture(0, moving ? renderTargetLow : renderTarget, ...) (Scene.cpp:450, :459; the two
+ * textures are made at Scene.cpp:405-415).  A context has two accumulation targets, 0 = the still image (selected at
+ * first) and 1 = the low-resolution preview the reference traces while the camera moves; each has its own size
+ * (rt_resize), sums and sample count.  rt_resize, rt_clear, rt_set_sum_buffer, rt_trace, rt_read_sum, rt_read_sum_static,
+ * rt_read_srgb8 and rt_accumulate_from work on the selected one; the other keeps what it has, so a host can trace a
+ * few preview frames and then carry on accumulating the still image. */
+int rt_select_target(rt_context *ctx, int target);
+
+/* What SAMPLE = 0 does to the reference's running mean (raytracer.glsl:611-613: the old value is weighted 0 / 1):
+ * the selected target starts over, sums and sample count zero.  Enqueued on the context's stream; nothing is
+ * reallocated. */
+int rt_clear(rt_context *ctx);
+
 /* Accumulate into caller-owned device memory (width*height float4, rgb = sums)
  * instead of the context's own buffer; NULL restores the internal one.  Lets a
  * host keep the buffer in a tensor it can hand to a collective. */

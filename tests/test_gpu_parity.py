@@ -785,11 +785,96 @@ def test_million_triangles_hierarchy_equals_loop(gpu_ctx, million_triangles):
             assert st[key] == wst[key], (pipeline, key)
 
 
-def test_million_triangles_full_size_forms_agree(gpu_ctx, million_triangles):
-    # 1920 x 1080 on the 1 M-triangle scene, 3 samples in one pass and in passes of 2 + 1: the library's own choice of
-    # forms (lane refill, budgeted shared searches, chunks handed out as waves become free, tail kernel on even slices)
-    # against every lane searching alone with every bounce staged, bit for bit, with equal counters
+@pytest.fixture(scope="module")
+def c3_layers():
+    # the 4096^2 albedo / normal / ARM layers of the measurement's 1 M-triangle workload
+    from gpuraytracer_amd import synthetic
+    return synthetic.texture_layers(4096)
+
+
+def _upload_c3_textures(target, layers):
+    target.set_atlas_size(4096)
+    for m in (0, 1):
+        for k in range(3):
+            target.upload_atlas_layer(m, k, layers[k])
+    target.set_has_texture(np.array([1, 1, 0], np.int32))
+
+
+def _c3_ray_batch(models, n, seed):
+    """Rays for the 1 M-triangle field: from the measurement's camera, from anywhere, aimed exactly at vertices, edge
+    midpoints and centroids (several triangles tie in depth there), parallel to an axis plane, and straight down."""
+    rng = np.random.default_rng(seed)
+    o = np.empty((n, 3)); d = np.empty((n, 3))
+    k = n // 5
+    o[:k] = np.array([0.0, 2.2, -5.5]) + rng.normal(0, 0.05, (k, 3))
+    d[:k] = rng.normal(0, 1, (k, 3)) * [0.6, 0.35, 0.2] + [0.0, -0.45, 0.9]
+    o[k:] = rng.uniform([-5, 0.5, -5], [5, 4, 5], (n - k, 3))
+    d[k:2 * k] = rng.normal(0, 1, (k, 3))
+    tri = rng.integers(0, len(models), 2 * k)
+    a = models["position"][tri].astype(np.float64)
+    b, c = a + models["u"][tri], a + models["v"][tri]
+    w = rng.integers(0, 4, 2 * k)[:, None]
+    target = np.where(w == 0, a, np.where(w == 1, 0.5 * (a + b), np.where(w == 2, 0.5 * (b + c), (a + b + c) / 3)))
+    d[2 * k:4 * k] = target - o[2 * k:4 * k]
+    d[4 * k:] = rng.normal(0, 1, (n - 4 * k, 3)) * [0.3, 0.3, 0.3] + [0.0, -1.0, 0.0]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o32, d32 = o.astype(np.float32), d.astype(np.float32)
+    flat = np.arange(4 * k, n)
+    d32[flat[0::3], 0] = 0.0            # exactly zero direction components: straight down, or in an axis plane
+    d32[flat[1::3], 2] = -0.0
+    d32[flat[2::6], 0] = 0.0
+    d32[flat[2::6], 2] = 0.0
+    return o32, d32
+
+
+def test_million_triangles_closest_hit_equals_checker(gpu_ctx, oracle_mod, million_triangles):
+    # the 1 M-triangle field against the CPU checker's loop over all triangles (the reference's findIntersection): what
+    # only scenes of 65 536 triangles or more use (leaves of two triangles, the hierarchy built by several threads, a
+    # depth beyond 20) has an independent witness here; ids and (u, v, t) bit for bit, loop form and hierarchy
+    models = million_triangles[0]
     _upload(gpu_ctx, million_triangles, gradient_env())
+    o, d = _c3_ray_batch(models, 4000, 17)
+    sc = oracle_mod.OracleScene(*million_triangles)
+    want_ids, want_uvt = sc.closest_hit_batch(o, d)
+    sc.close()
+    assert (want_ids >= 0).mean() > 0.7 and len(np.unique(want_ids)) > 2000
+    for accel in (0, 1):
+        gpu_ctx.set_option("accel", accel)
+        ids, uvt = gpu_ctx.closest_hit_batch(o, d)
+        assert np.array_equal(ids, want_ids), (accel, int((ids != want_ids).sum()))
+        hit = ids >= 0
+        assert np.array_equal(uvt[hit].view(np.uint32), want_uvt[hit].view(np.uint32)), accel
+
+
+def test_million_triangles_textured_render_equals_checker(gpu_ctx, oracle_mod, million_triangles, c3_layers):
+    # the measurement's 1 M-triangle workload as it is measured (4096^2 albedo / normal / ARM layers on two materials,
+    # the library's own choice of forms: lane refill, shared searches with a node budget, two-triangle leaves), small
+    # enough for the CPU checker: 48 x 32 pixels, two samples, sums and counters bit for bit
+    env = gradient_env()
+    cam = camera_matrix((0.0, 2.2, -5.5), (-0.45, 0.0))
+    _upload(gpu_ctx, million_triangles, env)
+    _upload_c3_textures(gpu_ctx, c3_layers)
+    sc = oracle_mod.OracleScene(*million_triangles)
+    sc.upload_env(env)
+    _upload_c3_textures(sc, c3_layers)
+    want, wst = sc.render(cam, 4711, 6, 1.0, 48, 32, 0, 2)
+    sc.close()
+    assert wst["rays"] > 1.1 * wst["pixel_samples"] and wst["shadow_probes"] > 200 and wst["glossy_probes"] > 200
+    for pipeline in (1, 5, 7):
+        img, st = _render(gpu_ctx, 48, 32, 0, 2, clock=4711, pipeline=pipeline, batch=2, cam=cam)
+        same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
+        assert same.all(), (pipeline, int((~same).sum()))
+        for key in ("pixel_samples", "rays", "shadow_probes", "glossy_probes"):
+            assert st[key] == wst[key], (pipeline, key)
+    gpu_ctx.set_atlas_size(4096)
+
+
+def test_million_triangles_full_size_forms_agree(gpu_ctx, million_triangles, c3_layers):
+    # 1920 x 1080 on the 1 M-triangle scene with its texture layers, 3 samples in one pass and in passes of 2 + 1: the
+    # library's own choice of forms (lane refill, budgeted shared searches, chunks handed out as waves become free, tail
+    # kernel on even slices) against every lane searching alone with every bounce staged, bit for bit, with equal counters
+    _upload(gpu_ctx, million_triangles, gradient_env())
+    _upload_c3_textures(gpu_ctx, c3_layers)
     cam = camera_matrix((0.0, 2.2, -5.5), (-0.45, 0.0))
     a, sa = _render(gpu_ctx, 1920, 1080, 0, 3, clock=99, pipeline=1, batch=3, cam=cam)
     b, sb = _render(gpu_ctx, 1920, 1080, 0, 3, clock=99, pipeline=7, batch=2, cam=cam)
@@ -798,6 +883,7 @@ def test_million_triangles_full_size_forms_agree(gpu_ctx, million_triangles):
     for key in ("rays", "shadow_probes", "glossy_probes", "pixel_samples"):
         assert sa[key] == sb[key], key
     assert sa["rays"] > 1.15 * sa["pixel_samples"] and np.isfinite(a).mean() > 0.999
+    gpu_ctx.set_atlas_size(4096)
 
 
 from exr_plain import read_exr_scanlines as _read_exr_scanlines  # noqa: E402

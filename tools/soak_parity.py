@@ -56,8 +56,40 @@ def case_for(seed, tmp, write_soup=None):
     return scene, cam, w, h, spp, rec, clock, batches
 
 
+def check_seed(ctx, seed, tmp, env, T, oracle=None, oracle_budget=4e9):
+    """Renders the case of one seed in the loop form and in four hierarchy forms (and with `oracle`, the CPU checker's
+    module, every fourth seed by the checker too, while triangles x pixel-samples stays under `oracle_budget`).
+    Returns (description, list of differences)."""
+    scene, cam, w, h, spp, rec, clock, batches = case_for(seed, tmp, T._write_soup)
+    T._upload(ctx, scene, env)
+    want, wst = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=3, batch=batches[0], cam=cam)
+    line = "seed %d: %d tris %dx%d spp %d rec %d rays %d" % (seed, len(scene[0]), w, h, spp, rec, wst["rays"])
+    diffs = []
+    for k, form in enumerate((1, 5, 7, 6)):
+        # queues for the whole pass, or for a fraction of it (passes that do not fit take further rounds)
+        rounds = (1, 3, 8, 2)[(seed + k) % 4]
+        img, st = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=form, batch=batches[k % 3 + 1], cam=cam,
+                            rounds=rounds)
+        same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
+        ok = same.all() and all(st[key] == wst[key] for key in ("rays", "shadow_probes", "glossy_probes"))
+        if not ok:
+            diffs.append("FORM %d DIFFERS (%d values)" % (form, int((~same).sum())))
+    if oracle is not None and seed % 4 == 0 and len(scene[0]) * w * h * spp < oracle_budget:
+        sc = oracle.OracleScene(*scene)
+        sc.upload_env(env)
+        ref, rst = sc.render(cam, clock, rec, 1.0, w, h, 0, spp)
+        sc.close()
+        same = (ref.view(np.uint32) == want.view(np.uint32)) | (np.isnan(ref) & np.isnan(want))
+        if not (same.all() and rst["rays"] == wst["rays"]):
+            diffs.append("CHECKER DIFFERS (%d values)" % int((~same).sum()))
+        else:
+            line += "  checker ok"
+    return line, diffs
+
+
 def main():
     import test_gpu_parity as T
+    from oracle import oracle
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     step = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -66,33 +98,10 @@ def main():
     tmp = tempfile.mkdtemp()
     env = gradient_env()
     for seed in range(first, first + count * step, step):
-        scene, cam, w, h, spp, rec, clock, batches = case_for(seed, tmp)
-        T._upload(ctx, scene, env)
-        want, wst = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=3, batch=batches[0], cam=cam)
-        line = "seed %d: %d tris %dx%d spp %d rec %d rays %d" % (seed, len(scene[0]), w, h, spp, rec, wst["rays"])
-        for k, form in enumerate((1, 5, 7, 6)):
-            # queues for the whole pass, or for a fraction of it (passes that do not fit take further rounds)
-            rounds = (1, 3, 8, 2)[(seed + k) % 4]
-            img, st = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=form, batch=batches[k % 3 + 1], cam=cam,
-                                rounds=rounds)
-            same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
-            ok = same.all() and all(st[key] == wst[key] for key in ("rays", "shadow_probes", "glossy_probes"))
-            if not ok:
-                bad += 1
-                line += "  FORM %d DIFFERS (%d values)" % (form, int((~same).sum()))
-        if seed % 4 == 0 and len(scene[0]) * w * h * spp < 4e9:
-            from oracle import oracle
-            sc = oracle.OracleScene(*scene)
-            sc.upload_env(env)
-            ref, rst = sc.render(cam, clock, rec, 1.0, w, h, 0, spp)
-            same = (ref.view(np.uint32) == want.view(np.uint32)) | (np.isnan(ref) & np.isnan(want))
-            if not (same.all() and rst["rays"] == wst["rays"]):
-                bad += 1
-                line += "  CHECKER DIFFERS (%d values)" % int((~same).sum())
-            else:
-                line += "  checker ok"
-        print(line, flush=True)
-    print("%d scenes, %d differences" % (count, bad))
+        line, diffs = check_seed(ctx, seed, tmp, env, T, oracle)
+        bad += len(diffs)
+        print(line + "".join("  " + d for d in diffs), flush=True)
+    print("%d scenes from seed %d (step %d), %d differences" % (count, first, step, bad))
     sys.exit(1 if bad else 0)
 
 
