@@ -6,17 +6,21 @@
 Workload (the configuration the headline metric is quoted on): the reference's bundled `cubes` scene (424 triangles, 24 of
 them emissive), 1920x1080, RECURSION 6, CLOCK 95834783, default camera, constant environment
 (the reference's .exr environment is not in its repository; data is synthetic in that sense).
-One step renders `--spp-per-step` samples per pixel in one pass (512 by default, the largest pass the library takes:
-132 GB of path queues at 1080p; passes of 256 samples, 66 GB, are 2.5 % slower); the default 4 steps are 2048 spp, and
-`seconds_per_1024spp` is the timed region scaled to the 1024 spp of the metric.  Rays = findIntersection
-executions (one per bounce entered); light probes are counted separately.
+The job is ONE image of steps x `--spp-per-step` samples per pixel (4 x 4096 = 16 384 spp by default), whatever the
+number of GPUs ("scaling": "strong", the form of the metric "seconds to N spp"): a step is the K-th part of the image's
+samples, rendered in passes of 512 samples (the largest pass the library takes: 132 GB of path queues at 1080p; passes
+of 256 samples, 66 GB, are 2.5 % slower), so that on 8 GPUs a rank's step is still one full pass.
+`seconds_per_1024spp` is the timed region, reduce included, scaled to the 1024 spp of the metric.  Rays =
+findIntersection executions (one per bounce entered); light probes are counted separately.
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) the scene is replicated and rank r renders
-SAMPLE = r, r + N, r + 2N, ...; the per-GPU radiance sums are gathered on rank 0 over RCCL and added there in rank
-order, inside the timed region.  Two modes:
-  default          every rank renders steps x spp-per-step samples ("scaling": "weak")
-  --total-spp T    the T samples of one image are split over the ranks ("scaling": "strong"; the step count follows
-                   from T); with --width 3840 --height 2160 --total-spp 4096 this is the 4K / 4096 spp configuration
+With N > 1 there is one rank per GPU: `python bench.py --gpus N` starts them itself (python -m torch.distributed.run,
+as a child process, before anything touches a GPU) unless it already runs under a launcher (RANK in the environment).
+The scene is replicated and rank r renders SAMPLE = r, r + N, r + 2N, ...; the per-GPU radiance sums are gathered on
+rank 0 over RCCL and added there in rank order, inside the timed region.  Modes:
+  default          the steps x spp-per-step samples of one image are split over the ranks ("scaling": "strong")
+  --total-spp T    the same with T samples in all (the step count follows from T); with --width 3840 --height 2160
+                   --total-spp 4096 this is the 4K / 4096 spp configuration
+  --weak           every rank renders steps x spp-per-step samples ("scaling": "weak")
 
 Other workloads (not the headline; `--workload`): `obiwan` = the bundled 12 030-triangle model at RECURSION 16,
 `c3` = a synthetic 1 M-triangle height field (gpuraytracer_amd/synthetic.py) ingested through the OBJ/MTL reader,
@@ -37,7 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H = 1920, 1080
-SPP_PER_STEP = 512          # samples per step and pass by default; the counter files under profiles/ are measured with it
+SPP_PER_STEP = 4096         # samples of the image per step by default
+SPP_PER_PASS = 512          # samples per pass by default; the counter files under profiles/ are measured with it
 # Vector-instruction issue of gfx950 as measured by tools/microbench_valu.hip (profiles/r02_valu_ceiling.txt): a SIMD
 # sustains one wave64 instruction per 2.32 clocks for v_fma/v_mul/v_add/v_mov/integer add/logic (and for mixes of those
 # with the slower kinds), one per 4.2 clocks for v_min/v_max/v_cmp/v_cndmask/shifts/conversions/packed f32.
@@ -149,15 +154,45 @@ def profile_counters(workload, kernel_key):
     return None, "profiles/%s has no kernel %s" % (name, kernel_key)
 
 
+def launch_command(n_gpus, argv, port, script=None):
+    """The command that starts one rank per GPU for `python bench.py --gpus N <argv>`."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n_gpus, argv, script=None):
+    """Starts the ranks as a child process (this process has not touched a GPU and does not, it only waits), hands rank 0's
+    JSON line on to standard output and returns the child's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver shares device memory between processes by dmabuf only
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.run(launch_command(n_gpus, argv, port, script), env=env, stdout=subprocess.PIPE)
+    lines = [l for l in child.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif child.returncode == 0:
+        sys.stderr.write("bench.py: the ranks ended without a result line\n")
+        return 1
+    return child.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP)
+    ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP,
+                    help="samples per pixel of the image that one step renders, all ranks together (with --weak: each rank)")
     ap.add_argument("--total-spp", type=int, default=0,
-                    help="strong scaling: split this many samples per pixel over the ranks (the step count follows from it)")
-    ap.add_argument("--batch-samples", type=int, default=SPP_PER_STEP, help="samples per pass (about 124 bytes of queue memory per pixel-sample of a pass)")
+                    help="samples per pixel of the image instead of steps x spp-per-step (the step count follows from it)")
+    ap.add_argument("--weak", action="store_true", help="every rank renders steps x spp-per-step samples (weak scaling)")
+    ap.add_argument("--batch-samples", type=int, default=SPP_PER_PASS, help="samples per pass (about 124 bytes of queue memory per pixel-sample of a pass)")
     ap.add_argument("--queue-rounds", type=int, default=-1, help="-1 library default; the path queues hold 1/N of a pass's paths")
     ap.add_argument("--pipeline", type=int, default=1)
     ap.add_argument("--accel", type=int, default=-1, help="-1 auto, 0 loops over all triangles, 1 hierarchy")
@@ -177,6 +212,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce-pass", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     global W, H
     W, H = args.width, args.height
 
@@ -194,9 +231,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
@@ -206,12 +240,17 @@ def main():
 
     scene, cam, RECURSION, workload_name, layers = load_workload(g, args)
     clock = g.DEFAULT_CLOCK
-    spp = args.spp_per_step
-    strong = args.total_spp > 0
+    strong = not args.weak
     if strong:
-        # this rank's share of the image's samples, rendered in steps of `spp`; every rank takes the same number of steps
-        plan = step_plan(args.total_spp, rank, world, spp)
+        # one image of total_spp samples; this rank's share of it, in steps of `spp` samples per rank (the K-th part of
+        # the share of rank 0); every rank takes the same number of steps
+        total_spp = args.total_spp if args.total_spp > 0 else args.steps * args.spp_per_step
+        n_steps = max(1, -(-args.total_spp // args.spp_per_step)) if args.total_spp > 0 else max(1, args.steps)
+        spp = max(1, -(-(-(-total_spp // world)) // n_steps))
+        plan = step_plan(total_spp, rank, world, spp)
     else:
+        spp = args.spp_per_step
+        total_spp = args.steps * spp * world
         plan = [(rank + world * (i * spp), spp, world) for i in range(args.steps)]
     steps = len(plan)
     my_count = sum(n for _, n, _ in plan)
@@ -314,7 +353,7 @@ def main():
             algo = (float(st["pixel_samples"]) - d1 - dp) * 12.0 + d1 * 64.0 + dp * 112.0
             achieved = algo / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
             prof, provenance = profile_counters(args.workload, "k_first<")
-            comparable = prof is not None and args.spp_per_step == SPP_PER_STEP and (W, H) == (1920, 1080)
+            comparable = prof is not None and min(args.batch_samples, spp) == SPP_PER_PASS and (W, H) == (1920, 1080)
             roof = {"bound": "hbm", "kernel": "k_first (depth 0: camera ray, closest hit by hierarchy, shading, "
                                               "light probe in place, rest of the bounce)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -355,7 +394,7 @@ def main():
         roof.update({"avg_launch_ms": ext_ms / ext_n, "launches": int(st["extend0_launches"]),
                      "probe_kernels_ms": st["probe_ms"], "extend_kernels_ms": st["extend_ms"],
                      "shade_kernels_ms": st["shade_ms"]})
-        spp_label = ("%d spp split over %d GPUs" % (args.total_spp, world)) if strong else "%d spp per GPU" % (steps * spp)
+        spp_label = ("%d spp split over %d GPUs" % (total_spp, world)) if strong and world > 1 else "%d spp per GPU" % (steps * spp)
         out = {
             "metric": "Mrays/s (paths x bounces) at 1080p" if (W, H) == (1920, 1080) else "Mrays/s (paths x bounces) at %dx%d" % (W, H),
             "value": rays / dt / 1e6,
@@ -367,13 +406,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s, %dx%d, RECURSION %d, %s (%d spp/step), constant environment"
-                                   % (workload_name, W, H, RECURSION, spp_label, spp),
+            "config": {"workload": "%s, %dx%d, RECURSION %d, %s (%d spp per step and GPU in passes of %d), constant environment"
+                                   % (workload_name, W, H, RECURSION, spp_label, spp, min(args.batch_samples, spp)),
                        "pipeline": "staged" if args.pipeline else "single-kernel",
                        "closest_hit": "hierarchy (exact)" if used_bvh else "loop over all triangles",
                        "parallelism": ("spp split x%d, sums gathered over RCCL and added in rank order" % world) if world > 1 else "1 GPU"},
-            "seconds_to_%dspp" % (args.total_spp if strong else steps * spp): dt,
-            "seconds_per_1024spp": dt * 1024.0 / float(args.total_spp if strong else steps * spp),
+            "seconds_to_%dspp" % total_spp: dt,
+            "seconds_per_1024spp": dt * 1024.0 / float(total_spp),
             "reduce_ms": reduce_ms if dist is not None else 0.0,
             "probe_rays_per_s_M": probes / dt / 1e6,
             "rays_per_pixel_sample": rays / max(1.0, float(st["pixel_samples"]) * world),

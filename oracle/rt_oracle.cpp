@@ -392,6 +392,7 @@ inline V3 sampleAtlas(const Scene &sc, float s, float t, uint32_t layer) {
 inline V3 skyColor(const Scene &sc, const Frame &fr, V3 direction) {
     const float s = m_atan2(direction.z, direction.x) * INV_PI * 0.5f + 0.5f;
     const float t = -m_asin(direction.y) * INV_PI + 0.5f;
+    if (orc_debug()) fprintf(stderr, "  sky: direction.y %.9g asin %.9g\n", direction.y, m_asin(direction.y));
     return sampleEnv(sc, s, t) * fr.exposure;
 }
 
@@ -532,6 +533,9 @@ V3 trace(const Scene &sc, const Frame &fr, Ray ray, uint32_t seed, uint32_t ligh
             occlusion = texel_arm.x;
             roughness = texel_arm.y;
             metallic = texel_arm.z;
+            if (orc_debug())
+                fprintf(stderr, "  textured: N %.9g %.9g %.9g T %.9g %.9g %.9g tex_normal %.9g %.9g %.9g -> normal %.9g %.9g %.9g\n",
+                        N.x, N.y, N.z, T.x, T.y, T.z, tex_normal.x, tex_normal.y, tex_normal.z, normal.x, normal.y, normal.z);
         }
         const float ior = material.emission_ior[3];
         const float variance = roughness * roughness;
@@ -545,6 +549,9 @@ V3 trace(const Scene &sc, const Frame &fr, Ray ray, uint32_t seed, uint32_t ligh
         const float transmission = (ior == 0.0f) ? 0.0f : getTransmission(cos_theta, 1.00029f, ior);
         // fma() of :497; Mesa: separate multiply and add
         const float fresnel_reflectance = (1.0f - transmission) * m_pow5(1.0f - cos_theta) + transmission;
+        if (orc_debug())
+            fprintf(stderr, "  fresnel: cos_theta %.9g (1 - cos^2 = %.9g) ior %.9g transmission %.9g reflectance %.9g\n", cos_theta,
+                    1.0f - cos_theta * cos_theta, ior, transmission, fresnel_reflectance);
 
         const float rand_reflectance = unitFloat(seed);
         const float rand_scatter = unitFloat(seed);
