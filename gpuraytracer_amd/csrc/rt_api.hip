@@ -41,6 +41,8 @@ struct rt_context {
     // hierarchies (all triangles; light triangles only), see rt_bvh.h
     struct DevBvh {
         float4 *nodes = nullptr, *leaf_geo = nullptr;
+        uint4 *qnodes = nullptr;
+        float qbase[3] = {0.0f, 0.0f, 0.0f}, qscale[3] = {1.0f, 1.0f, 1.0f};
         int *leaf_ids = nullptr;
         float max_abs = 0.0f;
         int n_nodes = 0, n_slots = 0, depth = 0;
@@ -139,6 +141,8 @@ constexpr int REFILL_AUTO_MIN = 65536;
 DBvh device_bvh(const rt_context *ctx, const rt_context::DevBvh &b, bool want) {
     DBvh d;
     d.nodes = b.nodes;
+    d.qnodes = b.qnodes;
+    for (int a = 0; a < 3; a++) { d.qbase[a] = b.qbase[a]; d.qscale[a] = b.qscale[a]; }
     d.leaf_geo = b.leaf_geo;
     d.leaf_ids = b.leaf_ids;
     d.max_abs_coord = b.max_abs;
@@ -161,12 +165,13 @@ bool use_accel(const rt_context *ctx) {
 // Do both hierarchies fit the LDS of a workgroup (KernelCfg::RES)?
 bool fits_lds(const rt_context *ctx) {
     const rt_context::DevBvh &a = ctx->bvh, &l = ctx->light_bvh;
-    const int bytes = RES_NODE_BYTES * (a.n_nodes + (l.ok ? l.n_nodes : 0)) + 64 * (a.n_slots + (l.ok ? l.n_slots : 0));
+    const int bytes = RES_NODE_BYTES * (a.n_nodes + (l.ok ? l.n_nodes : 0)) + 32 + 64 * (a.n_slots + (l.ok ? l.n_slots : 0));
     return bytes <= RES_BYTES && a.depth < RES_STACK && (!l.ok || l.depth < RES_STACK);
 }
 
 void free_bvh(rt_context::DevBvh &b) {
     if (b.nodes) (void)hipFree(b.nodes);
+    if (b.qnodes) (void)hipFree(b.qnodes);
     if (b.leaf_geo) (void)hipFree(b.leaf_geo);
     if (b.leaf_ids) (void)hipFree(b.leaf_ids);
     b = rt_context::DevBvh();
@@ -176,6 +181,9 @@ hipError_t upload_bvh(const rt_triangle_model *tris, uint32_t count, rt_context:
     HostBvh hb;
     build_bvh(tris, count, hb);
     hipError_t e = hipMalloc(&out.nodes, hb.nodes.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&out.qnodes, hb.qnodes.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(out.qnodes, hb.qnodes.data(), hb.qnodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    for (int a = 0; a < 3; a++) { out.qbase[a] = hb.qbase[a]; out.qscale[a] = hb.qscale[a]; }
     if (e == hipSuccess) e = hipMalloc(&out.leaf_geo, std::max<size_t>(1, hb.leaf_geo.size()) * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&out.leaf_ids, std::max<size_t>(1, hb.leaf_ids.size()) * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(out.nodes, hb.nodes.data(), hb.nodes.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -849,6 +857,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     s.bvh_probe_tris = ds.probe_tris;
     s.depth1_paths = ws[WSTAT_DEPTH1];
     s.deferred_probes = ws[WSTAT_DEFERRED];
+    s.parked_probes = ws[WSTAT_PARKED];
     s.queue_bytes = ctx->pipe.queue_bytes();
     *out = s;
     return RT_OK;

@@ -37,7 +37,13 @@
 namespace rt {
 
 struct DBvh {
-    const float4 *nodes;     // 4 x float4 per node
+    const float4 *nodes;     // 4 x float4 per node: the boxes in full precision (staged into LDS by resident hierarchies)
+    // The nodes as the traversal reads them from memory: 32 bytes each, the 12 box planes as 15-bit positions on a
+    // grid over the hierarchy's bounds, rounded outwards (see bvh_ray_setup).  2 x uint4 per node:
+    //   (x planes of child 0, of child 1, y planes of child 0, of child 1) (z planes of child 0, of child 1, link 0, link 1)
+    // a word of planes = lo | hi << 16, each 0x8000 | position.
+    const uint4 *qnodes;
+    float qbase[3], qscale[3];   // plane = qbase + position / 32768 * qscale
     const float4 *leaf_geo;  // 4 x float4 per leaf slot: triangle record + (index, -, -, -)
     const int *leaf_ids;
     float max_abs_coord;
@@ -79,10 +85,10 @@ struct BvhScratchT {
 };
 typedef BvhScratchT<false> BvhScratch;
 
-// Cooperative copy of the top of the hierarchy into LDS; every thread of the workgroup calls it.
+// Cooperative copy of the top of the hierarchy (32-byte nodes) into LDS; every thread of the workgroup calls it.
 RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top, int max_nodes = BVH_TOP_NODES) {
     const int n_top = bv.enabled ? (bv.n_nodes < max_nodes ? bv.n_nodes : max_nodes) : 0;
-    for (int i = threadIdx.x; i < n_top * 4; i += blockDim.x) top[i] = ((const v4f *)bv.nodes)[i];
+    for (int i = threadIdx.x; i < n_top * 2; i += blockDim.x) top[i] = ((const v4f *)bv.qnodes)[i];
     __syncthreads();
     return n_top;
 }
@@ -93,15 +99,23 @@ RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top, int max_nodes = BVH_TOP_NODES
 //   words 0..5   x: lo0 hi0 lo0 lo1 hi1 lo1      words 6..11  y, 12..17 z likewise
 //   words 18,19  child links: inner node = byte offset of its record, leaf = the (negative) leaf code as it is
 // That takes the 12 min/max of a node step away (they issue at half the rate of multiply-adds on this chip).
-constexpr int RES_NODE_BYTES = 80;
+#ifndef RT_RES_NODE_WORDS
+#define RT_RES_NODE_WORDS 20
+#endif
+constexpr int RES_NODE_WORDS = RT_RES_NODE_WORDS;     // 20 words of content; more = padding that changes the banks consecutive records start in
+constexpr int RES_NODE_BYTES = 4 * RES_NODE_WORDS;
+static_assert(RES_NODE_WORDS >= 20, "a resident node record holds 20 words");
+// 16-byte units the resident node records of a hierarchy take (what follows them is read with 16-byte accesses)
+RT_DEV int res_nodes_v4f(int n_nodes) { return (n_nodes * RES_NODE_WORDS + 3) / 4; }
 RT_DEV void bvh_stage_nodes_resident(const DBvh &bv, float *dst) {
-    const int n = bv.enabled ? bv.n_nodes * 20 : 0;
+    const int n = bv.enabled ? bv.n_nodes * RES_NODE_WORDS : 0;
     const float *src = (const float *)bv.nodes;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int node = i / 20, k = i - node * 20;
+        const int node = i / RES_NODE_WORDS, k = i - node * RES_NODE_WORDS;
         const float *s = src + 16 * node;        // (lo0.xyz, hi0.xyz, lo1.xyz, hi1.xyz, link0, link1, -, -)
-        float v;
-        if (k < 18) {
+        float v = 0.0f;
+        if (k >= 20) {
+        } else if (k < 18) {
             const int axis = k / 6, j = k - axis * 6;
             const int child = j / 3, which = (j - child * 3) == 1;      // 1 = hi
             v = s[6 * child + 3 * which + axis];
@@ -121,14 +135,20 @@ RT_DEV void bvh_stage_leaves(const DBvh &bv, v4f *leaves) {
 }
 
 struct BvhRay {
-    // plain form:    ca = (origin - r) * inv, cb = (origin + r) * inv: lo*inv - cb and hi*inv - ca widen the box by r
-    // resident form: ca = the constant of the plane met first, cb = of the plane met last (the two above, swapped where
-    //                the direction is negative); off = byte offsets into a node record that select (near, far) per axis
+    // Slab test of a box widened by r: entry distance along an axis = near * inv - ca, exit distance = far * inv - cb,
+    // where (near, far) are the box planes the ray meets first and last (which is which follows from the sign of its
+    // direction alone), ca = (origin + r') * inv, cb = (origin - r') * inv with r' = r signed like the direction.
+    // resident form: planes in scene units; off = byte offsets into a node record that select (near, far) per axis
+    // memory form:   planes as numbers F in [1, 2) (15-bit grid positions, see DBvh::qnodes): inv is the reciprocal
+    //                direction times the grid's extent and the constants hold the grid's origin; off = byte selectors
+    //                (v_perm_b32) that pick the near plane of a word of planes, ^ PERM_FLIP the far one
     f3 ca, cb;
     f3 inv;
     int off_x, off_y, off_z;
     bool finite;
 };
+constexpr uint32_t PERM_NEAR_LO = 0x0701000Cu, PERM_NEAR_HI = 0x0703020Cu, PERM_FLIP = 0x00020200u;
+constexpr uint32_t PLANE_EXPONENT = 0x3F000000u;       // with the position's 0x8000 in bit 23: 1.0f + position / 32768
 
 // Rays the box tests can serve: finite, and with the origin and the scene inside +-2^60, so that with |1/d| capped at
 // 2^64 (below) no product of a slab test overflows.  All others take the index-order loops.
@@ -142,7 +162,8 @@ RT_DEV bool bvh_ray_ok(const Ray &ray, float max_abs_coord) {
 }
 
 template <bool RES>
-RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
+RT_DEV BvhRay bvh_ray_setup(const Ray &ray, const DBvh &bv) {
+    const float max_abs_coord = bv.max_abs_coord;
     BvhRay b;
     const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y)),
                                     __builtin_fmaxf(__builtin_fabsf(ray.o.z), max_abs_coord));
@@ -172,38 +193,42 @@ RT_DEV BvhRay bvh_ray_setup(const Ray &ray, float max_abs_coord) {
         b.off_y = (int)((__float_as_uint(b.inv.y) >> 29) & 4u) + 24;
         b.off_z = (int)((__float_as_uint(b.inv.z) >> 29) & 4u) + 48;
     } else {
-        b.ca = mk3((ray.o.x - r) * b.inv.x, (ray.o.y - r) * b.inv.y, (ray.o.z - r) * b.inv.z);
-        b.cb = mk3((ray.o.x + r) * b.inv.x, (ray.o.y + r) * b.inv.y, (ray.o.z + r) * b.inv.z);
-        if (flat_x) { b.ca.x = -FAR; b.cb.x = FAR; }
-        if (flat_y) { b.ca.y = -FAR; b.cb.y = FAR; }
-        if (flat_z) { b.ca.z = -FAR; b.cb.z = FAR; }
-        b.off_x = b.off_y = b.off_z = 0;
+        // a plane is qbase + (F - 1) * qscale: F * (qscale * inv) - (origin +- r - (qbase - qscale)) * inv.  The rounding of
+        // these few operations on coordinates stays as far below the widening r as that of the plain form.
+        const float rx = __builtin_copysignf(r, b.inv.x), ry = __builtin_copysignf(r, b.inv.y), rz = __builtin_copysignf(r, b.inv.z);
+        const f3 o = mk3(ray.o.x - (bv.qbase[0] - bv.qscale[0]), ray.o.y - (bv.qbase[1] - bv.qscale[1]), ray.o.z - (bv.qbase[2] - bv.qscale[2]));
+        b.ca = mk3((o.x + rx) * b.inv.x, (o.y + ry) * b.inv.y, (o.z + rz) * b.inv.z);
+        b.cb = mk3((o.x - rx) * b.inv.x, (o.y - ry) * b.inv.y, (o.z - rz) * b.inv.z);
+        if (flat_x) { b.ca.x = FAR; b.cb.x = -FAR; }
+        if (flat_y) { b.ca.y = FAR; b.cb.y = -FAR; }
+        if (flat_z) { b.ca.z = FAR; b.cb.z = -FAR; }
+        b.inv = mk3(b.inv.x * bv.qscale[0], b.inv.y * bv.qscale[1], b.inv.z * bv.qscale[2]);
+        b.off_x = (int)((__float_as_uint(b.inv.x) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
+        b.off_y = (int)((__float_as_uint(b.inv.y) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
+        b.off_z = (int)((__float_as_uint(b.inv.z) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
     }
     b.finite = bvh_ray_ok(ray, max_abs_coord);
     return b;
 }
-// The address offsets of the resident form again, from the reciprocal direction (cheaper than carrying them to another lane).
+// The address offsets or byte selectors again, from the reciprocal direction (cheaper than carrying them to another lane).
+template <bool RES>
 RT_DEV void bvh_ray_offsets(BvhRay &b) {
-    b.off_x = (int)((__float_as_uint(b.inv.x) >> 29) & 4u);
-    b.off_y = (int)((__float_as_uint(b.inv.y) >> 29) & 4u) + 24;
-    b.off_z = (int)((__float_as_uint(b.inv.z) >> 29) & 4u) + 48;
+    if (RES) {
+        b.off_x = (int)((__float_as_uint(b.inv.x) >> 29) & 4u);
+        b.off_y = (int)((__float_as_uint(b.inv.y) >> 29) & 4u) + 24;
+        b.off_z = (int)((__float_as_uint(b.inv.z) >> 29) & 4u) + 48;
+    } else {
+        b.off_x = (int)((__float_as_uint(b.inv.x) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
+        b.off_y = (int)((__float_as_uint(b.inv.y) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
+        b.off_z = (int)((__float_as_uint(b.inv.z) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
+    }
 }
+// A plane of a 32-byte node as the number F = 1 + position / 32768: the two bytes `sel` picks, under a fixed exponent.
+RT_DEV float plane_of(uint32_t word, uint32_t sel) { return __uint_as_float(__builtin_amdgcn_perm(PLANE_EXPONENT, word, sel)); }
 
-// Slab test against a box widened by r (one fused multiply-add per plane; this test only has to be
-// conservative, it takes no part in the hit arithmetic).  Gives the entry distance (clamped at 0) and the exit
-// distance (clamped at `t_max`); the box is entered within t_max iff t_in <= t_out.  bvh_ray_setup keeps
-// infinities and NaN out of the terms.  The rounding of these
-// operations (a few 2^-24 of |origin| * |inv|) is below 1/16 of the widening r * |inv| = 2^-16 * |origin| * |inv|.
-RT_DEV void box_slabs(const BvhRay &br, f3 lo, f3 hi, float t_max, float &t_in, float &t_out) {
-    const float ax = __builtin_fmaf(lo.x, br.inv.x, -br.cb.x), bx = __builtin_fmaf(hi.x, br.inv.x, -br.ca.x);
-    const float ay = __builtin_fmaf(lo.y, br.inv.y, -br.cb.y), by = __builtin_fmaf(hi.y, br.inv.y, -br.ca.y);
-    const float az = __builtin_fmaf(lo.z, br.inv.z, -br.cb.z), bz = __builtin_fmaf(hi.z, br.inv.z, -br.ca.z);
-    t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
-                           __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
-    t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
-                            __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
-}
-
+// The slab tests (in bvh_advance) use one fused multiply-add per plane; they only have to be conservative and take no
+// part in the hit arithmetic.  bvh_ray_setup keeps infinities and NaN out of the terms.  The rounding of these operations
+// (a few 2^-24 of |origin| * |inv|) is below 1/16 of the widening r * |inv| = 2^-16 * |origin| * |inv|.
 struct BvhCounters { uint32_t nodes, tris; };
 // Counting the node visits and triangle tests costs the traversal loops one vector instruction per step and the
 // kernels four registers (1.4 % of the headline rate), so the product does not: the counters stay zero.  Two
@@ -280,16 +305,25 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
                 out1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(f1x, br.inv.x, -br.cb.x), __builtin_fmaf(f1y, br.inv.y, -br.cb.y)),
                                                        __builtin_fmaf(f1z, br.inv.z, -br.cb.z)), lim);
             } else {
-                v4f q0, q1, q2, q3;
+                v4f q0, q1;
                 if (node < ws.n_top) {
-                    q0 = ws.top[4 * node + 0]; q1 = ws.top[4 * node + 1]; q2 = ws.top[4 * node + 2]; q3 = ws.top[4 * node + 3];
+                    q0 = ws.top[2 * node + 0]; q1 = ws.top[2 * node + 1];
                 } else {
-                    const v4f *g = (const v4f *)bv.nodes;
-                    q0 = g[4 * node + 0]; q1 = g[4 * node + 1]; q2 = g[4 * node + 2]; q3 = g[4 * node + 3];
+                    const v4f *g = (const v4f *)bv.qnodes;
+                    q0 = g[2 * node + 0]; q1 = g[2 * node + 1];
                 }
-                box_slabs(br, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), lim, in0, out0);
-                box_slabs(br, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), lim, in1, out1);
-                c0 = __float_as_int(q3.x); c1 = __float_as_int(q3.y);
+                const uint32_t sx = (uint32_t)br.off_x, sy = (uint32_t)br.off_y, sz = (uint32_t)br.off_z;
+                const uint32_t x0 = __float_as_uint(q0.x), x1 = __float_as_uint(q0.y), y0 = __float_as_uint(q0.z), y1 = __float_as_uint(q0.w),
+                               z0 = __float_as_uint(q1.x), z1 = __float_as_uint(q1.y);
+                c0 = __float_as_int(q1.z); c1 = __float_as_int(q1.w);
+                in0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(plane_of(x0, sx), br.inv.x, -br.ca.x), __builtin_fmaf(plane_of(y0, sy), br.inv.y, -br.ca.y)),
+                                                      __builtin_fmaf(plane_of(z0, sz), br.inv.z, -br.ca.z)), 0.0f);
+                out0 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(plane_of(x0, sx ^ PERM_FLIP), br.inv.x, -br.cb.x), __builtin_fmaf(plane_of(y0, sy ^ PERM_FLIP), br.inv.y, -br.cb.y)),
+                                                       __builtin_fmaf(plane_of(z0, sz ^ PERM_FLIP), br.inv.z, -br.cb.z)), lim);
+                in1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(plane_of(x1, sx), br.inv.x, -br.ca.x), __builtin_fmaf(plane_of(y1, sy), br.inv.y, -br.ca.y)),
+                                                      __builtin_fmaf(plane_of(z1, sz), br.inv.z, -br.ca.z)), 0.0f);
+                out1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(plane_of(x1, sx ^ PERM_FLIP), br.inv.x, -br.cb.x), __builtin_fmaf(plane_of(y1, sy ^ PERM_FLIP), br.inv.y, -br.cb.y)),
+                                                       __builtin_fmaf(plane_of(z1, sz ^ PERM_FLIP), br.inv.z, -br.cb.z)), lim);
             }
             // the decisions as wave masks: their combinations then cost scalar instructions, and each
             // per-lane choice a single select
@@ -428,7 +462,7 @@ RT_DEV void closest_fold_redo(const DScene &sc, const Ray &ray, bool redo, int b
 template <class WS>
 RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, int begin_id, int end_id,
                            int current, float w_init, const WS &ws, f4 &isec, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv);
     ClosestFold cf;
     closest_fold_reset(cf, w_init);
     auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, current, cf); return true; };
@@ -464,7 +498,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
     lds_u8_ptr flags = scratch, table = scratch + 64;
     flags[lane] = 0;
     int owner = lane;
-    BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
+    BvhRay br = bvh_ray_setup<WS::RES>(ray, bv);
     TravState ts;
     trav_begin(ws, ts, active);
     auto leaf = [&](int slot) -> bool {
@@ -503,7 +537,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
             const float l2 = lane_read(lim, from4);
             if (takes) {
                 ray = r2; br.inv = b2.inv; br.ca = b2.ca; br.cb = b2.cb; extra = e2; lim = l2;
-                if (WS::RES) bvh_ray_offsets(br);
+                bvh_ray_offsets<WS::RES>(br);
                 owner = t_owner;
                 ts.node = t_node; ts.sp = 1; ts.run = true;
             }
@@ -518,7 +552,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
 template <class WS>
 RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
                                const WS &ws, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv);
     const bool ok = br.finite && ((max_t - max_t) == 0.0f);
     bool blocked = false;
     auto leaf = [&](int slot) -> bool {
@@ -542,7 +576,7 @@ RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
 template <class WS>
 RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, const f4 &isec, int current, bool active,
                                const WS &ws, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv.max_abs_coord);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv);
     const bool bounded = isec.z >= 0.0f;                 // a light was hit: only triangles not farther than it matter
     const float t_light = isec.z / isec.w;
     const bool ok = br.finite && (!bounded || (t_light - t_light) == 0.0f);
@@ -650,14 +684,12 @@ __global__ __launch_bounds__(64) void k_closest_hit_batch_bvh(DScene sc, DBvh bv
                                                               int *__restrict__ id, float *__restrict__ uvt,
                                                               DStats *__restrict__ stats) {
     __shared__ int stack_mem[BVH_STACK * 64];
-    __shared__ v4f top_mem[64 * 4];               // single-wave workgroups: a small top only
+    __shared__ v4f top_mem[128 * 2];              // single-wave workgroups: a small top only
     BvhScratch ws;
     ws.stack = stack_mem + threadIdx.x;
     ws.top = (lds_v4f_ptr)top_mem;
     ws.leaves = nullptr;
-    ws.n_top = bv.enabled ? (bv.n_nodes < 64 ? bv.n_nodes : 64) : 0;
-    for (int i = threadIdx.x; i < ws.n_top * 4; i += 64) top_mem[i] = ((const v4f *)bv.nodes)[i];
-    __syncthreads();
+    ws.n_top = bvh_stage_top(bv, top_mem, 128);
     BvhCounters cnt;
     cnt.nodes = 0; cnt.tris = 0;
     const unsigned long long chunks = (n + 63ull) / 64ull;

@@ -29,6 +29,8 @@ namespace rt {
 
 struct HostBvh {
     std::vector<float> nodes;          // 16 floats per node
+    std::vector<uint32_t> qnodes;      // 8 words per node: the same nodes with their planes on a 15-bit grid (quantise_nodes)
+    float qbase[3] = {0.0f, 0.0f, 0.0f}, qscale[3] = {1.0f, 1.0f, 1.0f};
     std::vector<float> leaf_geo;       // 16 floats per leaf slot: the 12 of the triangle record, its index, padding
     std::vector<int32_t> leaf_ids;     // original triangle index per leaf slot
     int depth = 0;
@@ -335,10 +337,57 @@ inline void reorder_breadth_first(HostBvh &b) {
     b.nodes.swap(nodes);
 }
 
+// The 32-byte form of the nodes that the traversal reads from memory: every box plane as a 15-bit position on a grid
+// over the bounds of the whole hierarchy, lower planes rounded down and upper planes up, so that a quantised box
+// contains its box.  A word holds the two planes of one child along one axis, lo | hi << 16, each 0x8000 | position:
+// under the exponent byte 0x3F the two bytes read as the float 1 + position / 32768 (rt_bvh.h: plane_of), and
+// plane = qbase + position / 32768 * qscale.  Node = (x of child 0, x of child 1, y, y, z, z, link 0, link 1).
+// A grid step is 1/32768 of the scene's extent: 2 to 4 % of a triangle's size in a regular mesh of a million triangles.
+inline void quantise_nodes(HostBvh &b) {
+    const size_t n = b.nodes.size() / 16;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t k = 0; k < n; k++)
+        for (int c = 0; c < 2; c++)
+            for (int a = 0; a < 3; a++) {
+                const float l = b.nodes[16 * k + 6 * c + a], h = b.nodes[16 * k + 6 * c + 3 + a];
+                if (std::isfinite(l) && std::isfinite(h) && l <= h) { lo[a] = std::min(lo[a], (double)l); hi[a] = std::max(hi[a], (double)h); }
+            }
+    for (int a = 0; a < 3; a++) {
+        if (!(lo[a] <= hi[a])) { lo[a] = 0.0; hi[a] = 0.0; }
+        const double ext = hi[a] - lo[a];
+        b.qbase[a] = std::nextafterf((float)lo[a], -INFINITY);
+        // a little more than the extent, so that the upper bound lies below the last grid position
+        b.qscale[a] = (float)std::max((hi[a] - (double)b.qbase[a]) * (1.0 + 1.0 / 1024.0), std::max(std::fabs(lo[a]), std::fabs(hi[a])) * 1e-6 + 1e-30);
+        (void)ext;
+    }
+    b.qnodes.assign(n * 8, 0u);
+    for (size_t k = 0; k < n; k++) {
+        for (int c = 0; c < 2; c++)
+            for (int a = 0; a < 3; a++) {
+                const float l = b.nodes[16 * k + 6 * c + a], h = b.nodes[16 * k + 6 * c + 3 + a];
+                uint32_t ql = 32767u, qh = 0u;       // an empty box stays empty: no ray enters it
+                if (l <= h) {
+                    const double base = b.qbase[a], scale = b.qscale[a];
+                    double pl = std::floor(((double)l - base) / scale * 32768.0), ph = std::ceil(((double)h - base) / scale * 32768.0);
+                    pl = std::min(std::max(pl, 0.0), 32767.0);
+                    ph = std::min(std::max(ph, 0.0), 32767.0);
+                    // as the device decodes them (exactly, up to what the widening of the boxes per ray covers)
+                    while (pl > 0.0 && base + pl / 32768.0 * scale > (double)l) pl -= 1.0;
+                    while (ph < 32767.0 && base + ph / 32768.0 * scale < (double)h) ph += 1.0;
+                    ql = (uint32_t)pl;
+                    qh = (uint32_t)ph;
+                }
+                b.qnodes[8 * k + 2 * a + c] = (0x8000u | ql) | ((0x8000u | qh) << 16);
+            }
+        memcpy(&b.qnodes[8 * k + 6], &b.nodes[16 * k + 12], 8);
+    }
+}
+
 inline void build_bvh(const rt_triangle_model *tris, uint32_t count, HostBvh &out) {
     build_bvh_impl(tris, count, false, out);
     if (out.depth >= BVH_STACK_DEPTH - 2) build_bvh_impl(tris, count, true, out);
     reorder_breadth_first(out);
+    quantise_nodes(out);
 }
 
 }  // namespace rt

@@ -102,6 +102,10 @@ constexpr uint32_t N_XCD = 8;
 #ifndef RT_DYNAMIC_SHARE_LARGE
 #define RT_DYNAMIC_SHARE_LARGE 1
 #endif
+#ifndef RT_FIXED_GROUP
+#define RT_FIXED_GROUP 1
+#endif
+constexpr uint32_t FIXED_GROUP = RT_FIXED_GROUP;         // consecutive chunks a wave renders in the fixed part of a pass
 constexpr uint32_t RUNS_PER_XCD = RT_RUNS_PER_XCD, N_RUNS = N_XCD * RUNS_PER_XCD;
 constexpr uint32_t CHUNK_BLOCK = RT_CHUNK_BLOCK;        // consecutive chunks that stay in one run
 // 1/share of the rounds of the depth-0 kernel is handed out as waves become free (PipeBuffers::dynamic_share): a third
@@ -204,8 +208,8 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
     if (!CFG::BVH) return;
     if (CFG::RES) {
         // node records are 80 bytes = 5 float4, leaf records 4 float4
-        v4f *nodes = scene_mem, *leaves = nodes + 5 * bv.n_nodes;
-        v4f *lnodes = leaves + 4 * bv.n_slots, *lleaves = lnodes + 5 * lbv.n_nodes;
+        v4f *nodes = scene_mem, *leaves = nodes + res_nodes_v4f(bv.n_nodes);
+        v4f *lnodes = leaves + 4 * bv.n_slots, *lleaves = lnodes + res_nodes_v4f(lbv.n_nodes);
         bvh_stage_nodes_resident(bv, (float *)nodes);
         ws.n_top = bv.n_nodes;
         ws.leaves = (lds_v4f_ptr)leaves;
@@ -220,27 +224,27 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
         share = (lds_u8_ptr)share_mem + 128 * wv;
     } else {
         // The stacks take what the depth of the hierarchies asks for (bv.stack_entries per lane) and the rest of the
-        // array caches nodes: the first ones of the light hierarchy (all of it if it has up to 128 nodes and a third
-        // of the room suffices) and, in what is left, the first ones of the scene's.  The waves' exchange areas are
-        // the last 16 node slots.
+        // array caches 32-byte nodes: the first ones of the light hierarchy (all of it if it has up to 256 nodes and a
+        // third of the room suffices) and, in what is left, the first ones of the scene's.  The waves' exchange areas are
+        // the last 1024 bytes.
         const int entries = bv.stack_entries;
         ws.stack = stack_mem + wv * (entries * 64) + lane;
         v4f *free_mem = (v4f *)(stack_mem + WG_WAVES * entries * 64);
-        const int room = (CFG::STACK_INTS - WG_WAVES * entries * 64) / 16 - 16;        // 64-byte node slots
+        const int room = (CFG::STACK_INTS - WG_WAVES * entries * 64) / 8 - 32;         // 32-byte node slots
         int light_slots = 0;
         if (with_light && lbv.enabled) {
-            light_slots = lbv.n_nodes < 128 ? lbv.n_nodes : 128;
+            light_slots = lbv.n_nodes < 256 ? lbv.n_nodes : 256;
             if (light_slots > room / 3) light_slots = room / 3;
         }
         const int scene_slots = room - light_slots;
-        v4f *light_top = free_mem + scene_slots * 4;
+        v4f *light_top = free_mem + scene_slots * 2;
         ws.top = (lds_v4f_ptr)free_mem;
         ws.n_top = bvh_stage_top(bv, free_mem, scene_slots);
         lws = ws;
         lws.top = (lds_v4f_ptr)light_top;
         lws.n_top = 0;
         if (with_light) lws.n_top = bvh_stage_top(lbv, light_top, light_slots);
-        share = (lds_u8_ptr)(free_mem + room * 4) + 128 * wv;
+        share = (lds_u8_ptr)(free_mem + room * 2) + 128 * wv;
     }
 }
 #define RT_TRAVERSAL_LDS(CFG)                                              \
@@ -308,13 +312,13 @@ struct PipeBuffers {
     unsigned long long *pool_map;               // [PIPE_WAVES / 64] one bit per region whose pool may have blocks left (k_extend)
     uint32_t region_cap;
     uint32_t round, rounds;                     // round of the pass these launches belong to, and how many it has (see MAX_ROUNDS)
-    uint32_t defer_below;                       // depth-0 chunks with fewer probes than this leave them to the probe stages; 0: never
+    uint32_t defer_below;                       // a probe search of the depth-0 kernel wants this many lanes, else the chunk parks its probes; 0: never
     uint32_t dynamic_share;                     // 1/dynamic_share of the depth-0 kernel's rounds is handed out as waves become free
     unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
 };
 
 enum { WSTAT_PATHS = 0, WSTAT_RAYS, WSTAT_SHADOW, WSTAT_GLOSSY, WSTAT_EXT_NODES, WSTAT_EXT_TRIS, WSTAT_PROBE_NODES,
-       WSTAT_PROBE_TRIS, WSTAT_DEPTH1, WSTAT_DEFERRED, WSTAT_SLOTS = 16 };
+       WSTAT_PROBE_TRIS, WSTAT_DEPTH1, WSTAT_DEFERRED, WSTAT_PARKED, WSTAT_SLOTS = 16 };
 
 constexpr uint32_t KEPT_DIFF = 1u, KEPT_SPEC = 2u;      // kept flags
 constexpr uint32_t CURRENT_MASK = 0x3FFFFFFFu;
@@ -649,6 +653,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     uint32_t n_rays = 0;
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
+#if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS == 3
+    unsigned long long xclk[4] = {0, 0, 0, 0};
+#endif
 
     BlockFeed feed;
     feed_begin(feed, b, b.n_ext[q_in], b.claim, POOL_SHARE);
@@ -656,6 +663,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
         // foreign blocks only while this wave's regions can take all their paths (what goes to the probe regions may come
         // on to the next extend region)
         uint32_t src, src_total, block;
+#if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS == 3
+        unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
         if (!feed_next(feed, b, fill.next + fill.shadow + fill.glossy + 64u * STEAL_BLOCKS <= b.region_cap, src, src_total, block)) break;
         const uint32_t qi = block * 64u + lane;
         const bool live = qi < src_total;
@@ -664,24 +674,47 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
         load_path_rec(b, q_in, (size_t)src * b.region_cap + (live ? qi : 0u), ps, id, kept_flags);
         n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
+#if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS == 3
+        // measurement build: cycles spent getting a block and its records, in the closest hit, in shading and routing
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+        xclk[0] += t1_ - t0_;
+#endif
         f4 isec;
         const int hit = closest_hit_cfg<CFG>(sc, bv, ray, live, ws, isec, bc);
+#if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS == 3
+        unsigned long long t2_ = __builtin_amdgcn_s_memtime();
+        xclk[1] += t2_ - t1_;
+#endif
         const float inv_det = 1.0f / isec.w;
         shade_and_route(sc, fr, b, depth, q_in, tab, paths_per_sample, max_depth, live, id, ps, kept_flags, hit,
                         isec.x * inv_det, isec.y * inv_det, isec.z * inv_det, fill);
+#if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS == 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xclk[2] += __builtin_amdgcn_s_memtime() - t2_;
+        xclk[3] += 1;
+#endif
     }
     store_route_fill(b, q_in, fill);
     wstat_add(b, WSTAT_RAYS, n_rays);
+#if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS == 3
+    wstat_add(b, WSTAT_EXT_NODES, xclk[0]);
+    wstat_add(b, WSTAT_EXT_TRIS, xclk[1]);
+    wstat_add(b, WSTAT_PROBE_NODES, xclk[2]);
+    wstat_add(b, WSTAT_PROBE_TRIS, xclk[3]);
+#else
     if (CFG::BVH) {
         wstat_add(b, WSTAT_EXT_NODES, wave_sum_u32(bc.nodes));
         wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
     }
+#endif
 }
 
-// Depth-0 chunks with fewer probes than this leave them to the probe stages of depth 0 (PipeBuffers::defer_below); scenes
-// from DEFER_MAX_TRIANGLES triangles on do not (their probe searches are long whatever the lanes' neighbours do).
+// A probe search of the depth-0 kernel runs with at least this many lanes (own probes + parked records taken up by idle
+// lanes); a chunk that cannot muster them parks its probes (PipeBuffers::defer_below, see k_first).  Scenes from
+// DEFER_MAX_TRIANGLES triangles on do not park (their probe searches are long whatever the lanes' neighbours do).
 #ifndef RT_DEFER_BELOW
-#define RT_DEFER_BELOW 32
+#define RT_DEFER_BELOW 48
 #endif
 constexpr uint32_t DEFER_BELOW = RT_DEFER_BELOW;
 constexpr int DEFER_MAX_TRIANGLES = 65536;
@@ -709,7 +742,8 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
     uint32_t n_paths = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
-    uint32_t q_shadow = 0, q_glossy = 0;       // probes left to the probe stages of depth 0 (DEFER_BELOW)
+    uint32_t q_shadow = 0, q_glossy = 0;       // probe records parked in this wave's region at present
+    uint32_t n_parked = 0;                     // ... and how many were ever written
     const bool deeper = 1 < max_depth;
 
 #if defined(RT_SECTION_CLOCKS) && RT_SECTION_CLOCKS > 0
@@ -718,6 +752,12 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
 #else
 #define SECTION_MARK(k) do { } while (0)
 #define RT_SECTION_CLOCKS 0
+#endif
+#ifndef RT_PROBE_HISTO
+#define RT_PROBE_HISTO 0
+#endif
+#if RT_PROBE_HISTO > 0
+    unsigned long long histo[4] = {0, 0, 0, 0};
 #endif
     // A chunk is one tile of one sample.  Chunks are numbered tile-major (all samples of a tile follow each other), so
     // that the waves at work at the same time are on few tiles: the nodes and triangles under a tile are fetched once
@@ -739,7 +779,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     // wait, the image does not depend on it.  The counter value for the next chunk is fetched while the current chunk
     // is rendered.
     const uint32_t n_rounds = (n_chunks + (uint32_t)PIPE_WAVES - 1u) / (uint32_t)PIPE_WAVES;
-    const uint32_t fixed_rounds = RT_DYNAMIC_CHUNKS ? n_rounds - n_rounds / b.dynamic_share : n_rounds;
+    // (a whole number of groups of FIXED_GROUP rounds: in the fixed part a wave renders FIXED_GROUP consecutive chunks, i.e.
+    // samples of one tile, before it moves on, so that the probe records a chunk parks are taken up by a chunk of the same tile)
+    const uint32_t fixed_rounds = (RT_DYNAMIC_CHUNKS ? n_rounds - n_rounds / b.dynamic_share : n_rounds) / FIXED_GROUP * FIXED_GROUP;
     const uint32_t fixed_chunks = fixed_rounds * (uint32_t)PIPE_WAVES;          // may exceed n_chunks when nothing is left
     const uint32_t n_blocks = n_chunks > fixed_chunks ? (n_chunks - fixed_chunks + CHUNK_BLOCK - 1u) / CHUNK_BLOCK : 0u;
     const uint32_t home = (blockIdx.x % N_XCD) * RUNS_PER_XCD + (blockIdx.x / N_XCD) % RUNS_PER_XCD;
@@ -766,7 +808,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         uint32_t chunk;
         if (round < fixed_rounds) {
             if (fill_next + q_shadow + q_glossy + 64u > b.region_cap) { stalled = true; break; }
-            chunk = round * (uint32_t)PIPE_WAVES + first;
+            chunk = ((round / FIXED_GROUP) * (uint32_t)PIPE_WAVES + first) * FIXED_GROUP + round % FIXED_GROUP;
             round++;
         } else {
             uint32_t c;
@@ -833,57 +875,128 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         }
         SECTION_MARK(1);
         Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
+        float probe_max_t = bn.max_t;
         ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
         uint32_t kept_flags = 0;
         bool go_on = false;
-        // A chunk with few probes (a tile at the edge of an object) would run the search with most lanes idle: its probes
-        // are left to the probe stages of depth 0, which run them packed with those of other chunks.
-        bool deferred = false;
+        // The chunk's probes.  All lanes of a chunk want the same kind of probe, but not all of them want one: sky pixels
+        // do not, and sampleLight gives up before its loop for every light triangle that faces away (half of them, lane
+        // by lane).  A search with a third or half of the lanes idle wastes that share of the wave, so probes are PARKED
+        // and TAKEN UP AGAIN: a chunk with too few probes writes them to the wave's region of the probe queue as records
+        // (as the deeper bounces do for every probe) and goes on to the next chunk; in a later chunk of the same kind
+        // the lanes that have no probe of their own retire their path first and then take a parked record each, search
+        // for it and finish its bounce.  A search runs when own probes + records that fit the idle lanes reach
+        // b.defer_below (or the regions are too full to park more).  Records still parked when the kernel ends are left
+        // to the probe stages of depth 0.  Which lane finishes a path does not change its arithmetic.
+        const bool wants = shaded && bn.kind == (coin_diffuse ? PROBE_SHADOW : PROBE_GLOSSY);
+        bool parked = false, host = false;
+        bool own_retired = false;       // wave-uniform: the lanes without a probe have retired their own paths before the search
+        uint32_t path_id = id;          // the path a lane finishes after the search: its own, or that of the record it took up
+        int path_hit = hit;
+        size_t rec = 0;
         if (b.defer_below) {
-            const bool wants = shaded && bn.kind == (coin_diffuse ? PROBE_SHADOW : PROBE_GLOSSY);
-            const uint32_t n_wants = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(wants));
-            // (only while the wave's regions are at most 7/8 full: these records must not be what makes a pass need a further round)
-            if (n_wants != 0u && n_wants < b.defer_below && 8u * (fill_next + q_shadow + q_glossy + 64u) <= 7u * b.region_cap) {
-                deferred = wants;
-                const size_t region = (size_t)wave * b.region_cap;
-                const uint32_t slot = region_slot(coin_diffuse ? q_shadow : q_glossy, wants);
-                if (wants) store_probe_rec(b, coin_diffuse ? region + slot : region + (b.region_cap - 1u - slot), ps, id, hit, 0u, bn, coin_diffuse);
-                shaded = shaded && !wants;       // the probe stage goes on with these paths
+            uint32_t &pending = coin_diffuse ? q_shadow : q_glossy;
+            const unsigned long long want_mask = __builtin_amdgcn_ballot_w64(wants);
+            const uint32_t n_wants = (uint32_t)__popcll(want_mask);
+            const uint32_t n_take = pending < 64u - n_wants ? pending : 64u - n_wants;
+            const size_t region = (size_t)wave * b.region_cap;
+            // (parking only while the wave's regions are at most 7/8 full: these records must not be what makes a pass need a further round)
+            const bool room = 8u * (fill_next + q_shadow + q_glossy + 64u) <= 7u * b.region_cap;
+            if (n_wants + n_take < b.defer_below && room) {
+                if (n_wants != 0u) {
+                    parked = wants;
+                    const uint32_t slot = region_slot(pending, wants);
+                    if (wants) store_probe_rec(b, coin_diffuse ? region + slot : region + (b.region_cap - 1u - slot), ps, id, hit, 0u, bn, coin_diffuse);
+                    n_parked += n_wants;
+                }
+            } else if (n_take != 0u) {
+                // the own paths of the lanes without a probe end their bounce now (the probe function returned false, or the
+                // ray left the scene): these lanes are free then
+                bool own_on = false;
+                if (shaded && !wants) {
+                    f4 none;
+                    none.x = none.y = none.z = 0.0f; none.w = 1.0f;
+                    own_on = (coin_diffuse ? finish_diffuse(sc, ps, hit, false, bn.lit, bn.albedo, bn.roughness)
+                                           : finish_glossy(sc, fr, ps, hit, 0, bn.probe_d, -1, none, bn.c, bn.w)) && deeper;
+                }
+                route_next(b, 1, fill_next, live && !wants, own_on, ps, id, 0u);
+                own_retired = true;
+                const unsigned long long idle = ~want_mask;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                host = !wants && rank < n_take;
+                // the records were written by other lanes of this wave: their stores have to be done before they are read
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (host) {
+                    const uint32_t k = pending - 1u - rank;          // the records parked last are taken first
+                    rec = coin_diffuse ? region + k : region + (b.region_cap - 1u - k);
+                    const float4 a = b.pa[rec], pr = b.p0[rec];
+                    probe.o = mk3(a.x, a.y, a.z);
+                    probe.d = mk3(pr.x, pr.y, pr.z);
+                    probe_max_t = pr.w;
+                    path_hit = (int)(b.pd[rec].z & CURRENT_MASK);
+                }
+                pending -= n_take;
             }
         }
+        const bool run = (wants && !parked) || host;
+#if RT_PROBE_HISTO > 0
+        // measurement build: searches of the depth-0 kernel by the number of lanes they run with (1: shadow, 2: glossy)
+        if ((RT_PROBE_HISTO == 1) == coin_diffuse) {
+            const uint32_t n_run = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
+            if (n_run) histo[n_run < 48u ? n_run / 16u : 3u]++;
+        }
+#endif
+        // the lanes that finish a path after the search
+        const bool fin = own_retired ? run : (shaded && !parked);
+        f3 lit = bn.lit, colour = coin_diffuse ? bn.albedo : bn.c;
+        float factor = coin_diffuse ? bn.roughness : bn.w;
         if (coin_diffuse) {
-            const bool run = shaded && bn.kind == PROBE_SHADOW;
             bool blocked = true;
             if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                blocked = shadow_any_hit_cfg<CFG>(sc, bv, probe, bn.max_t, hit, run, ws, share, pc);
+                blocked = shadow_any_hit_cfg<CFG>(sc, bv, probe, probe_max_t, path_hit, run, ws, share, pc);
                 n_shadow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             }
             SECTION_MARK(2);
-            if (shaded) {
+            if (host) {     // the rest of the record
+                load_probe_path(b, rec, ps);
+                const uint4 d = b.pd[rec];
+                const float4 c = b.p1[rec], al = b.p2[rec];
+                ps.seed = d.x; path_id = d.y;
+                lit = mk3(c.x, c.y, c.z); factor = c.w;
+                colour = mk3(al.x, al.y, al.z);
+            }
+            if (fin) {
                 const bool written = run && !blocked;
-                go_on = finish_diffuse(sc, ps, hit, written, bn.lit, bn.albedo, bn.roughness) && deeper;
+                go_on = finish_diffuse(sc, ps, path_hit, written, lit, colour, factor) && deeper;
                 // the kept light result matters to later bounces only
-                if (written && go_on) { b.kd[id] = make_float4(bn.lit.x, bn.lit.y, bn.lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
+                if (written && go_on) { b.kd[path_id] = make_float4(lit.x, lit.y, lit.z, 0.0f); kept_flags |= KEPT_DIFF; }
             }
         } else {
-            const bool run = shaded && bn.kind == PROBE_GLOSSY;
             int outcome = 0, light_id = -1;
             f4 lsec;
             lsec.x = lsec.y = lsec.z = 0.0f; lsec.w = 1.0f;
             if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
-                outcome = glossy_search_cfg<CFG>(sc, bv, lbv, probe, hit, run, light_id, lsec, ws, lws, share, pc);
+                outcome = glossy_search_cfg<CFG>(sc, bv, lbv, probe, path_hit, run, light_id, lsec, ws, lws, share, pc);
                 n_glossy += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             }
             SECTION_MARK(RT_SECTION_CLOCKS == 2 ? 3 : 2);     // 2: the glossy probe is booked on the last slot
-            if (shaded) {
-                go_on = finish_glossy(sc, fr, ps, hit, run ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w) && deeper;
+            if (host) {
+                load_probe_path(b, rec, ps);
+                const uint4 d = b.pd[rec];
+                const float4 c = b.p1[rec];
+                ps.seed = d.x; path_id = d.y;
+                colour = mk3(c.x, c.y, c.z); factor = c.w;
+            }
+            if (fin) {
+                go_on = finish_glossy(sc, fr, ps, path_hit, run ? outcome : 0, probe.d, light_id, lsec, colour, factor) && deeper;
                 if (run && outcome != 0 && go_on) {
-                    b.ks[id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
+                    b.ks[path_id] = make_float4(ps.kept_spec.x, ps.kept_spec.y, ps.kept_spec.z, 0.0f);
                     kept_flags |= KEPT_SPEC;
                 }
             }
         }
-        route_next(b, 1, fill_next, live && !deferred, go_on, ps, id, kept_flags);
+        route_next(b, 1, fill_next, own_retired ? run : (live && !parked), go_on, ps, path_id, kept_flags);
         SECTION_MARK(3);
     }
     if (lane == 0) {
@@ -897,9 +1010,18 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     wstat_add(b, WSTAT_RAYS, n_paths);
     wstat_add(b, WSTAT_DEPTH1, fill_next);
     wstat_add(b, WSTAT_DEFERRED, q_shadow + q_glossy);
+    wstat_add(b, WSTAT_PARKED, n_parked);
     wstat_add(b, WSTAT_SHADOW, n_shadow);
     wstat_add(b, WSTAT_GLOSSY, n_glossy);
-#if RT_SECTION_CLOCKS > 0
+#if RT_PROBE_HISTO > 0
+    // measurement build: the four hierarchy counters carry the numbers of searches with 1-15, 16-31, 32-47, 48-64 lanes instead
+    wstat_add(b, WSTAT_EXT_NODES, histo[0]);
+    wstat_add(b, WSTAT_EXT_TRIS, histo[1]);
+    wstat_add(b, WSTAT_PROBE_NODES, histo[2]);
+    wstat_add(b, WSTAT_PROBE_TRIS, histo[3]);
+#elif RT_SECTION_CLOCKS == 3
+    // (measurement build of the extend stage: the counters are its own)
+#elif RT_SECTION_CLOCKS > 0
     // measurement build: the four hierarchy counters carry the cycles of the four sections instead
     wstat_add(b, WSTAT_EXT_NODES, clk[0]);
     wstat_add(b, WSTAT_EXT_TRIS, clk[1]);
@@ -1246,7 +1368,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     trav_begin(ws, ts, false);
     Ray ray;
     ray.o = ray.d = mk3(0.0f, 0.0f, 0.0f);
-    BvhRay br = bvh_ray_setup<CFG::RES>(ray, bv.max_abs_coord);
+    BvhRay br = bvh_ray_setup<CFG::RES>(ray, bv);
     ClosestFold cf;
     closest_fold_reset(cf, 1.0f);
     for (;;) {
@@ -1256,7 +1378,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
             const float4 a = b.xa[q_in][i], c = b.xb[q_in][i];
             ray.o = mk3(a.x, a.y, a.z);
             ray.d = mk3(a.w, c.x, c.y);
-            br = bvh_ray_setup<CFG::RES>(ray, bv.max_abs_coord);
+            br = bvh_ray_setup<CFG::RES>(ray, bv);
             closest_fold_reset(cf, 1.0f);
             busy = true;
             ts.node = 0; ts.sp = 1; ts.run = br.finite;

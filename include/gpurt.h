@@ -84,6 +84,8 @@ typedef struct rt_stats {
     uint64_t depth1_paths;      /* camera paths that went on to a second bounce (staged form; else 0) */
     uint64_t queue_bytes;       /* device memory the path queues of the staged form hold at present */
     uint64_t deferred_probes;   /* light probes of depth 0 that the depth-0 kernel left to the probe kernels (as 112-byte records) */
+    uint64_t parked_probes;     /* light probes of depth 0 that the depth-0 kernel wrote as records: those it took up again itself with
+                                 * idle lanes of later chunks, and the deferred ones */
 } rt_stats;
 
 typedef struct rt_context rt_context;

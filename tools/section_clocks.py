@@ -29,3 +29,21 @@ c = np.array([st["bvh_extend_nodes"], st["bvh_extend_tris"], st["bvh_probe_nodes
 print(name, "paths", st["pixel_samples"], "probes", st["shadow_probes"] + st["glossy_probes"], "k_first ms", st["extend0_ms"])
 for label, v in zip(("closest hit", "shade_pre", "probe", "finish+route"), c):
     print("  %-13s %5.1f %%   %.0f cycles per wave-tile" % (label, 100 * v / c.sum(), v / (st["pixel_samples"] / 64)))
+
+# Library built with -DRT_SECTION_CLOCKS=3: the counters carry the cycles of the extend stage (bounces after the first)
+# instead: getting a block and its records | closest hit | shading and routing | blocks.  Shown when the argument
+# "extend" follows the scene name.
+if len(sys.argv) > 2 and sys.argv[2] == "extend":
+    ctx.set_frame(g.camera_matrix(), g.DEFAULT_CLOCK, 6 if name == "cubes" else 16, 1.0)
+    ctx.set_option("batch_samples", 512)
+    ctx.trace(0, 512, 1)
+    torch.cuda.synchronize()
+    ctx.reset_stats()
+    ctx.trace(512, 512, 1)
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    c = np.array([st["bvh_extend_nodes"], st["bvh_extend_tris"], st["bvh_probe_nodes"]], dtype=np.float64)
+    blocks = float(st["bvh_probe_tris"])
+    print(name, "extend stage: blocks", blocks, "extend ms (incl. depth 0)", st["extend_ms"], "depth 0 ms", st["extend0_ms"])
+    for label, v in zip(("block + records", "closest hit", "shade + route"), c):
+        print("  %-16s %5.1f %%   %.0f cycles per block of 64" % (label, 100 * v / c.sum(), v / blocks))
