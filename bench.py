@@ -43,14 +43,23 @@ sys.path.insert(0, ROOT)
 W, H = 1920, 1080
 SPP_PER_STEP = 4096         # samples of the image per step by default
 SPP_PER_PASS = 512          # samples per pass by default; the counter files under profiles/ are measured with it
-# Vector-instruction issue of gfx950 as measured by tools/microbench_valu.hip (profiles/r02_valu_ceiling.txt): a SIMD
-# sustains one wave64 instruction per 2.32 clocks for v_fma/v_mul/v_add/v_mov/integer add/logic (and for mixes of those
+# Vector-instruction issue of gfx950: a SIMD issues a wave64 instruction over 2 clocks (32 lanes per clock; the
+# architectural rate, MI355X_MICROARCH.md).  Measured by tools/microbench_valu.hip (profiles/r03_valu_ceiling.txt), 8
+# waves per SIMD, whole chip: one per 2.32 clocks for v_fma/v_mul/v_add/v_mov/integer add/logic (and for mixes of those
 # with the slower kinds), one per 4.2 clocks for v_min/v_max/v_cmp/v_cndmask/shifts/conversions/packed f32.
+VALU_ARCH_CLOCKS = 2.0
 VALU_FAST_CLOCKS = 2.32
+VALU_SLOW_CLOCKS = 4.2
 SIMDS, CLOCK_HZ = 1024, 2.4e9
-# FP32 rate of unfused multiplies and adds (the intersection arithmetic may not contract): one flop per lane and
-# instruction at the fast issue rate above
-PEAK_VALU_TFLOPS = SIMDS * 64 * CLOCK_HZ / VALU_FAST_CLOCKS / 1e12
+# one operation per lane and vector instruction (the intersection arithmetic may not fuse multiply-adds): 32 lanes per
+# clock and SIMD
+PEAK_LANE_TOPS = SIMDS * 32 * CLOCK_HZ / 1e12
+PEAK_VALU_TFLOPS = PEAK_LANE_TOPS
+L2_PEAK_GBPS = 34500.0          # all 8 XCDs (MI355X_MICROARCH.md)
+# vector instructions of a traversal step (assembly listing of the traversal loops): a node step of the hierarchy resident in
+# LDS, of the hierarchy read from memory (12 byte-selects more: its planes are 15-bit grid positions), a triangle test
+# (17 to the plane test, 24 more to the inside test)
+INSTS_NODE_RESIDENT, INSTS_NODE_MEMORY, INSTS_TRIANGLE = 36, 48, 41
 FLOPS_PER_CLOSEST_TEST = 35     # raytracer.glsl:135-158, full pass
 FLOPS_PER_PROBE_TEST = 34       # raytracer.glsl:171-195
 
@@ -134,11 +143,14 @@ def load_workload(g, args):
             % (len(scene[0]), args.atlas), layers)
 
 
+PROFILE_ROUND = "r03"
+
+
 def profile_counters(workload, kernel_key):
     """Per-launch counters of one kernel from rocprofv3 passes over this command (separate --pmc runs, made by
     tools/prof_bench.sh and tools/prof_summary.py and kept under profiles/): FETCH_SIZE_KB (to be doubled: gfx950
     reports half of wide reads), WRITE_SIZE_KB, vector instructions.  Returns (counters, provenance) or (None, why)."""
-    name = "r02_pmc_counters_%s.json" % workload
+    name = "%s_pmc_counters_%s.json" % (PROFILE_ROUND, workload)
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             table = json.load(f)
@@ -349,41 +361,109 @@ def main():
             # radiance record per path that ended, a 64-byte path record per path that goes on (depth1_paths counts those,
             # the ones among the deferred probes included: an upper bound by that much), a 112-byte probe record per
             # probe left to the probe kernels.
-            d1, dp = float(st["depth1_paths"]), float(st["deferred_probes"])
-            algo = (float(st["pixel_samples"]) - d1 - dp) * 12.0 + d1 * 64.0 + dp * 112.0
+            d1, dp, pk = float(st["depth1_paths"]), float(st["deferred_probes"]), float(st["parked_probes"])
+            algo = (float(st["pixel_samples"]) - d1 - dp) * 12.0 + d1 * 64.0 + pk * 112.0 + (pk - dp) * 112.0
             achieved = algo / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
             prof, provenance = profile_counters(args.workload, "k_first<")
             comparable = prof is not None and min(args.batch_samples, spp) == SPP_PER_PASS and (W, H) == (1920, 1080)
-            roof = {"bound": "hbm", "kernel": "k_first (depth 0: camera ray, closest hit by hierarchy, shading, "
-                                              "light probe in place, rest of the bounce)",
-                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": (2.0 * prof["FETCH_SIZE_KB"] + prof["WRITE_SIZE_KB"]) * 1024.0 if comparable else None,
-                    "traffic_source": provenance if comparable else "not measured for this configuration (%s)" % provenance,
-                    "bytes_per_launch": algo / ext_n,
-                    "note": "bound by vector instruction issue and the latency of dependent LDS accesses, not by "
-                            "bandwidth: see valu_issue"}
-            if comparable and ext_ms > 0 and "TCC_HIT_sum" in prof:
+            launch_s = ext_ms / ext_n * 1e-3 if ext_ms > 0 else 0.0
+            traffic = (2.0 * prof["FETCH_SIZE_KB"] + prof["WRITE_SIZE_KB"]) * 1024.0 if comparable else None
+            kernel_name = ("k_first (depth 0: camera ray, closest hit by hierarchy, shading, light probe in place with parked "
+                           "probes taken up by idle lanes, rest of the bounce)")
+            memory_path = {"algorithmic_bytes_per_launch": algo / ext_n, "achieved_GBps": achieved, "hbm_peak_GBps": 8000.0,
+                           "hbm_frac": achieved / 8000.0,
+                           "note": "12 B per path that ended, 64 B per path that goes on, 112 B written per parked probe and "
+                                   "read back per probe taken up again"}
+            if comparable and launch_s > 0 and "TCC_HIT_sum" in prof:
                 # what the same counter passes say about the memory path during a launch: bytes that crossed the fabric side
-                # of the L2s (HBM or Infinity Cache) per second, the L2 hit rate, and how busy the CUs' vector memory
-                # front ends (texture addressers) were; hierarchies that do not fit LDS/L2 are bound there
-                launch_s = ext_ms / ext_n * 1e-3
-                roof["memory_path"] = {
-                    "beyond_l2_GBps": roof["traffic"] / launch_s / 1e9,
-                    "beyond_l2_frac_of_hbm_peak": roof["traffic"] / launch_s / 1e9 / 8000.0,
-                    "l2_requests_per_launch": prof["TCC_HIT_sum"] + prof["TCC_MISS_sum"],
-                    "l2_hit_rate": prof["TCC_HIT_sum"] / max(1.0, prof["TCC_HIT_sum"] + prof["TCC_MISS_sum"]),
+                # of the L2s (HBM or Infinity Cache) per second, the L2 requests and hit rate, and how busy the CUs' vector
+                # memory front ends (texture addressers) were; hierarchies that do not fit LDS/L2 are bound there
+                requests = prof["TCC_HIT_sum"] + prof["TCC_MISS_sum"]
+                memory_path.update({
+                    "beyond_l2_GBps": traffic / launch_s / 1e9,
+                    "beyond_l2_frac_of_hbm_peak": traffic / launch_s / 1e9 / 8000.0,
+                    "l2_requests_per_launch": requests,
+                    "l2_hit_rate": prof["TCC_HIT_sum"] / max(1.0, requests),
+                    # a request moves 64 or 128 bytes (FETCH_SIZE tallies them at 64): the lower figure
+                    "l2_GBps": requests * 64.0 / launch_s / 1e9,
+                    "l2_peak_GBps": L2_PEAK_GBPS,
+                    "l2_frac": requests * 64.0 / launch_s / 1e9 / L2_PEAK_GBPS,
                     "vector_memory_busy_frac": prof.get("TA_BUSY_avr", 0.0) / max(1.0, prof.get("gpu_cycles", 0.0)) or None,
-                    "source": provenance}
-            if comparable and ext_ms > 0:
-                # vector instructions of one launch (counter pass) over the live launch time, against the issue rate a
-                # SIMD sustains (profiles/r02_valu_ceiling.txt)
-                peak = SIMDS * CLOCK_HZ / VALU_FAST_CLOCKS / 1e9
-                rate = prof["valu_wave_insts"] / (ext_ms / ext_n * 1e-3) / 1e9
-                roof["valu_issue"] = {"bound": "valu", "achieved": rate, "peak": peak, "unit": "G wave-instructions/s",
-                                      "frac": rate / peak, "wave_insts_per_launch": prof["valu_wave_insts"],
-                                      "peak_source": "profiles/r02_valu_ceiling.txt: one wave64 instruction per %.2f clocks "
-                                                     "and SIMD (4.2 for min/max/compare/select), 1024 SIMDs, 2.4 GHz" % VALU_FAST_CLOCKS,
-                                      "insts_source": provenance}
+                    "source": provenance})
+            valu_issue = None
+            if comparable and launch_s > 0:
+                # vector instructions of one launch (counter pass) over the live launch time, against the rate at which a SIMD
+                # issues wave64 instructions
+                peak = SIMDS * CLOCK_HZ / VALU_ARCH_CLOCKS / 1e9
+                rate = prof["valu_wave_insts"] / launch_s / 1e9
+                valu_issue = {"achieved": rate, "peak": peak, "unit": "G wave-instructions/s", "frac": rate / peak,
+                              "frac_of_measured_fast_rate": rate / (SIMDS * CLOCK_HZ / VALU_FAST_CLOCKS / 1e9),
+                              "clocks_per_instruction_and_simd": SIMDS * CLOCK_HZ / (rate * 1e9),
+                              "wave_insts_per_launch": prof["valu_wave_insts"],
+                              "peak_source": "architectural: a wave64 instruction issues over %.0f clocks on a SIMD, 1024 SIMDs, 2.4 GHz; "
+                                             "measured on this chip (profiles/r03_valu_ceiling.txt): %.2f clocks for fma/mul/add/mov/"
+                                             "integer add/logic, %.1f for min/max/compare/select/shift/convert, so a loop that is "
+                                             "40 %% of the slow kind cannot issue faster than one per 3.1 clocks"
+                                             % (VALU_ARCH_CLOCKS, VALU_FAST_CLOCKS, VALU_SLOW_CLOCKS),
+                              "insts_source": provenance}
+            # Useful work: the vector lane-operations the algorithm needs (node steps and triangle tests of every lane's own
+            # ray, counted by the measurement build of the library in a depth-0-only render) over the lane-operations the chip
+            # could have issued in the launch time.  Idle lanes of a wave, bookkeeping and waiting are what is missing to 1.
+            useful = None
+            want_lanes = args.lane_utilisation != 0 and world == 1 and args.workload in ("cubes", "obiwan")
+            if want_lanes and launch_s > 0:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import lane_utilisation
+                first = lane_utilisation.measure(args.workload, 1)         # RECURSION 1: the depth-0 kernel alone
+                resident = args.workload == "cubes" and args.resident != 0
+                n_node = INSTS_NODE_RESIDENT if resident else INSTS_NODE_MEMORY
+                scale = (float(st["pixel_samples"]) / ext_n) / float(first["pixel_samples"])      # a launch against the 32 spp counted
+                own = lambda key: (first["bvh_extend_" + key]["steps"] + first["bvh_probe_" + key]["steps"]) * scale
+                spent = lambda key: (first["bvh_extend_" + key]["lane_slots"] + first["bvh_probe_" + key]["lane_slots"]) * scale
+                lane_ops = own("nodes") * n_node + own("tris") * INSTS_TRIANGLE
+                slot_ops = spent("nodes") * n_node + spent("tris") * INSTS_TRIANGLE
+                peak_ops = launch_s * PEAK_LANE_TOPS * 1e12
+                useful = {"traversal_lane_ops_per_launch": lane_ops, "traversal_frac": lane_ops / peak_ops,
+                          "traversal_lane_slots_frac": slot_ops / peak_ops,
+                          "traversal_lane_utilisation": lane_ops / max(1.0, slot_ops),
+                          "instructions_per_node_step": n_node, "instructions_per_triangle_test": INSTS_TRIANGLE,
+                          "source": "node steps and triangle tests of a RECURSION 1 render of 32 spp with gpuraytracer_amd/"
+                                    "libgpurt_steps.so (every lane's own steps) and libgpurt_wavesteps.so (lane slots spent), "
+                                    "scaled to the samples of a launch; instruction counts from the assembly listing"}
+                if valu_issue is not None:
+                    # what the launch issued beyond the traversal loops (shading, random numbers, queue records): counted as
+                    # useful at full waves, which it nearly is at depth 0 (an upper bound)
+                    other = max(0.0, prof["valu_wave_insts"] - slot_ops / 64.0) * 64.0
+                    useful["other_lane_ops_per_launch_upper"] = other
+                    useful["with_shading_upper_frac"] = (lane_ops + other) / peak_ops
+            frac = useful["with_shading_upper_frac"] if useful and "with_shading_upper_frac" in useful else (useful["traversal_frac"] if useful else None)
+            if frac is not None:
+                roof = {"bound": "valu", "kernel": kernel_name,
+                        "achieved": frac * PEAK_LANE_TOPS, "peak": PEAK_LANE_TOPS, "unit": "TFLOP/s", "frac": frac,
+                        "traffic": traffic,
+                        "traffic_source": provenance if comparable else "not measured for this configuration (%s)" % provenance,
+                        "note": "useful vector lane-operations per second (one per lane and instruction: the hit arithmetic may "
+                                "not fuse multiply-adds) against 1024 SIMDs x 32 lanes x 2.4 GHz; `frac` counts everything "
+                                "outside the traversal loops as useful (upper bound), useful.traversal_frac counts the "
+                                "traversal alone; the scene's hierarchy is in LDS, HBM only carries the path records "
+                                "(memory_path)" if args.workload == "cubes" else
+                                "useful vector lane-operations per second against 1024 SIMDs x 32 lanes x 2.4 GHz (upper bound: "
+                                "everything outside the traversal loops counted as useful); the hierarchy is read through L1/L2 "
+                                "(memory_path)"}
+            else:
+                roof = {"bound": "hbm", "kernel": kernel_name,
+                        "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                        "traffic": traffic,
+                        "traffic_source": provenance if comparable else "not measured for this configuration (%s)" % provenance,
+                        "note": "no traversal step counts for this configuration (they need the measurement builds and a bundled "
+                                "scene): algorithmic bytes against HBM; the kernel waits for node and leaf records that miss "
+                                "LDS and L1 (memory_path, valu_issue)"}
+            roof["bytes_per_launch"] = algo / ext_n
+            roof["memory_path"] = memory_path
+            if valu_issue is not None:
+                roof["valu_issue"] = valu_issue
+            if useful is not None:
+                roof["useful"] = useful
         else:
             flops = float(st["pixel_samples"]) * len(scene[0]) * FLOPS_PER_CLOSEST_TEST
             achieved = flops / (ext_ms * 1e-3) / 1e12 if ext_ms > 0 else 0.0

@@ -30,7 +30,8 @@ class RtStats(ctypes.Structure):
                 ("extend0_launches", ctypes.c_uint64), ("bvh_extend_nodes", ctypes.c_uint64),
                 ("bvh_extend_tris", ctypes.c_uint64), ("bvh_probe_nodes", ctypes.c_uint64),
                 ("bvh_probe_tris", ctypes.c_uint64), ("depth1_paths", ctypes.c_uint64), ("queue_bytes", ctypes.c_uint64),
-                ("deferred_probes", ctypes.c_uint64), ("parked_probes", ctypes.c_uint64)]
+                ("deferred_probes", ctypes.c_uint64), ("parked_probes", ctypes.c_uint64),
+                ("skipped_samples", ctypes.c_uint64)]
 
 
 class GpuRtError(RuntimeError):

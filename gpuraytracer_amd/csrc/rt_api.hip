@@ -81,6 +81,7 @@ struct rt_context {
     int resident = -1;         // -1 auto (hierarchies that fit are staged into LDS whole), 0 never
     int tonemap = 0;           // rt_read_srgb8: 0 sRGB transfer (displayQuad.fs), 1 ACES film curve first (Scene::exportBMP)
     int refill = -1;           // -1 auto (lane refill from REFILL_AUTO_MIN triangles on), 0 off, 1 on
+    int skip_nonfinite = 0;    // 1: samples whose radiance is NaN or infinite are left out of the sums and counted
 
     // stats
     DStats *d_stats = nullptr;
@@ -632,6 +633,7 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
 
     ctx->frame.width = ctx->width;
     ctx->frame.height = ctx->height;
+    ctx->frame.skip_nonfinite = ctx->skip_nonfinite ? 1u : 0u;
     const DScene sc = device_scene(ctx);
 
     // samples are processed in passes of at most `batch_samples`; the tables of a pass travel in the kernel arguments
@@ -692,7 +694,7 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
         } else {
             const char *msg = nullptr;
             const hipError_t e = ctx->pipe.run(sc, device_bvh(ctx, ctx->bvh, acc), device_bvh(ctx, ctx->light_bvh, acc), ctx->frame,
-                                               ctx->d_sum, tab, ctx->stream, ctx->profiling != 0, form, &ctx->host_stats, &msg);
+                                               ctx->d_sum, tab, ctx->stream, ctx->profiling != 0, form, &ctx->host_stats, ctx->d_stats, &msg);
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, "rt_trace: %s: %s",
                             msg ? msg : "pipeline", hipGetErrorString(e));
@@ -858,6 +860,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     s.depth1_paths = ws[WSTAT_DEPTH1];
     s.deferred_probes = ws[WSTAT_DEFERRED];
     s.parked_probes = ws[WSTAT_PARKED];
+    s.skipped_samples = ds.skipped;
     s.queue_bytes = ctx->pipe.queue_bytes();
     *out = s;
     return RT_OK;
@@ -899,6 +902,8 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "tonemap")) {
         if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "tonemap must be 0 or 1");
         ctx->tonemap = (int)value;
+    } else if (!strcmp(name, "skip_nonfinite")) {
+        ctx->skip_nonfinite = value ? 1 : 0;
     } else if (!strcmp(name, "share")) {
         ctx->share = value ? 1 : 0;
     } else if (!strcmp(name, "staged_depths")) {

@@ -91,6 +91,7 @@ struct DFrame {
     int recursion;
     float exposure;
     uint32_t width, height;
+    uint32_t skip_nonfinite;      // option "skip_nonfinite": samples whose radiance is NaN or infinite are not added to the sums
 };
 
 struct Ray { f3 o, d; };
@@ -301,7 +302,8 @@ RT_DEV f3 sample_env(const DScene &sc, float s, float t) {
 
 RT_DEV f3 sample_atlas(const DScene &sc, float s, float t, uint32_t layer) {
     if (layer >= (uint32_t)sc.atlas_layers) return mk3(0.0f, 0.0f, 0.0f);
-    const uint32_t *tx = sc.atlas[layer];
+    // (a pointer read from memory: told to be device memory, the texel reads are global loads, not generic-address ones)
+    const __attribute__((address_space(1))) uint32_t *tx = (const __attribute__((address_space(1))) uint32_t *)sc.atlas[layer];
     if (tx == nullptr) return mk3(0.0f, 0.0f, 0.0f);
     const int S = sc.atlas_size;
     const Bilinear bl = bilinear_setup(s, t, S, S);

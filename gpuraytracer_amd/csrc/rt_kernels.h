@@ -14,7 +14,10 @@ struct DStats {
     unsigned long long pixel_samples, rays, shadow_probes, glossy_probes;
     // hierarchy traversal work: node visits and triangle tests of the closest-hit and of the probe stages
     unsigned long long ext_nodes, ext_tris, probe_nodes, probe_tris;
+    unsigned long long skipped;       // pixel-samples left out of the sums (option "skip_nonfinite")
 };
+// NaN or infinite in any channel (x - x is NaN for both)
+RT_DEV bool nonfinite3(float x, float y, float z) { return !(((x - x) + (y - y)) + (z - z) == 0.0f); }
 
 // The per-pass table travels by value in the kernel arguments (2 KB), so a pass needs no host-to-device copy and no
 // staging buffer: the SAMPLE of slot k of the batch is first_sample + k * stride, and light_seed[k] is its light seed =
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 
     const uint32_t ty = (tile / tiles_x) * 8u + (lane >> 3);
     const bool in_image = (tx < fr.width) && (ty < fr.height);
 
-    uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0, n_paths = 0;
+    uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0, n_paths = 0, n_skipped = 0;
     f3 acc = mk3(0.0f, 0.0f, 0.0f);
     const size_t pix = (size_t)ty * fr.width + tx;
     if (in_image) {
@@ -273,9 +276,14 @@ __global__ __launch_bounds__(64) void k_trace_mega(DScene sc, DFrame fr, float4 
                     alive = finish_glossy(sc, fr, ps, bn.current, run ? outcome : 0, bn.probe_d, light_id, lsec, bn.c, bn.w);
             }
         }
-        acc = acc + ps.energy;
+        if (fr.skip_nonfinite && nonfinite3(ps.energy.x, ps.energy.y, ps.energy.z)) n_skipped += in_image ? 1u : 0u;
+        else acc = acc + ps.energy;
     }
     if (in_image) sum[pix] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    if (fr.skip_nonfinite) {
+        const unsigned long long k = wave_sum_u32(n_skipped);
+        if (lane == 0 && k) atomicAdd(&stats->skipped, k);
+    }
 
     const unsigned long long r = wave_sum_u32(n_rays), s = wave_sum_u32(n_shadow), g = wave_sum_u32(n_glossy),
                              p = wave_sum_u32(n_paths);

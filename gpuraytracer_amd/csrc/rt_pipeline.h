@@ -103,7 +103,7 @@ constexpr uint32_t N_XCD = 8;
 #define RT_DYNAMIC_SHARE_LARGE 1
 #endif
 #ifndef RT_FIXED_GROUP
-#define RT_FIXED_GROUP 1
+#define RT_FIXED_GROUP 8
 #endif
 constexpr uint32_t FIXED_GROUP = RT_FIXED_GROUP;         // consecutive chunks a wave renders in the fixed part of a pass
 constexpr uint32_t RUNS_PER_XCD = RT_RUNS_PER_XCD, N_RUNS = N_XCD * RUNS_PER_XCD;
@@ -1400,20 +1400,31 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     wstat_add(b, WSTAT_EXT_TRIS, wave_sum_u32(bc.tris));
 }
 
-// Resolve stage: sum[pixel] += radiance of the batch's samples, ascending slot order.
+// Resolve stage: sum[pixel] += radiance of the batch's samples, ascending slot order.  SKIP: samples whose radiance is
+// not finite are counted and left out (option "skip_nonfinite"; the reference adds them, which poisons the pixel).
+template <bool SKIP>
 __global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restrict__ sum, uint32_t width,
-                                                 uint32_t height, uint32_t paths_per_sample, uint32_t n_slots) {
+                                                 uint32_t height, uint32_t paths_per_sample, uint32_t n_slots,
+                                                 DStats *__restrict__ stats) {
     const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= width * height) return;
-    const uint32_t tx = pix % width, ty = pix / width;
-    const uint32_t tiles_x = (width + 7u) >> 3, tiles_y = (height + 7u) >> 3;
-    const uint32_t local = tile_number(tx >> 3, ty >> 3, tiles_x, tiles_y) * 64u + (ty & 7u) * 8u + (tx & 7u);
-    float4 s = sum[pix];
-    for (uint32_t k = 0; k < n_slots; k++) {
-        const Radiance e = b.energy[(size_t)k * paths_per_sample + local];
-        s.x += e.x; s.y += e.y; s.z += e.z;
+    const bool in_image = pix < width * height;
+    uint32_t skipped = 0;
+    if (in_image) {
+        const uint32_t tx = pix % width, ty = pix / width;
+        const uint32_t tiles_x = (width + 7u) >> 3, tiles_y = (height + 7u) >> 3;
+        const uint32_t local = tile_number(tx >> 3, ty >> 3, tiles_x, tiles_y) * 64u + (ty & 7u) * 8u + (tx & 7u);
+        float4 s = sum[pix];
+        for (uint32_t k = 0; k < n_slots; k++) {
+            const Radiance e = b.energy[(size_t)k * paths_per_sample + local];
+            if (SKIP && nonfinite3(e.x, e.y, e.z)) { skipped++; continue; }
+            s.x += e.x; s.y += e.y; s.z += e.z;
+        }
+        sum[pix] = s;
     }
-    sum[pix] = s;
+    if (SKIP) {
+        const unsigned long long n = wave_sum_u32(skipped);
+        if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&stats->skipped, n);
+    }
 }
 
 // What a pass may use, decided by the caller from the scene and the options.
@@ -1596,15 +1607,15 @@ struct Pipeline {
     template <class CFG>
     hipError_t launch_pass(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                            const PassTables &tab, hipStream_t stream, bool profiling, const PassForm &form, rt_stats *host_stats,
-                           const char **what);
+                           DStats *dstats, const char **what);
     hipError_t run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum, const PassTables &tab,
-                   hipStream_t stream, bool profiling, const PassForm &form, rt_stats *host_stats, const char **what);
+                   hipStream_t stream, bool profiling, const PassForm &form, rt_stats *host_stats, DStats *dstats, const char **what);
 };
 
 template <class CFG>
 inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                                         const PassTables &tab, hipStream_t stream, bool profiling, const PassForm &form,
-                                        rt_stats *host_stats, const char **what) {
+                                        rt_stats *host_stats, DStats *dstats, const char **what) {
     const int max_depth = fr.recursion > 1 ? fr.recursion : 1;
     const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
     const uint32_t pps = tiles * 64u;
@@ -1678,8 +1689,12 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
             PIPE_TRY(stamp(-1));
         }
     }
-    hipLaunchKernelGGL(k_resolve, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
-                       fr.height, pps, tab.n);
+    if (fr.skip_nonfinite)
+        hipLaunchKernelGGL(k_resolve<true>, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
+                           fr.height, pps, tab.n, dstats);
+    else
+        hipLaunchKernelGGL(k_resolve<false>, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
+                           fr.height, pps, tab.n, dstats);
     PIPE_TRY(hipGetLastError());
 #undef PIPE_TRY
     return hipSuccess;
@@ -1687,13 +1702,13 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
 
 inline hipError_t Pipeline::run(const DScene &sc, const DBvh &bvh, const DBvh &light_bvh, const DFrame &fr, float4 *sum,
                                 const PassTables &tab, hipStream_t stream, bool profiling, const PassForm &form,
-                                rt_stats *host_stats, const char **what) {
+                                rt_stats *host_stats, DStats *dstats, const char **what) {
     const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.height + 7u) >> 3);
     const size_t paths = (size_t)tiles * 64u * (size_t)tab.n;
     if (paths > 0xFFFFFFF0ull) { *what = "batch has more than 2^32 paths"; return hipErrorInvalidValue; }
     if (paths > cap_paths || (form.bvh && form.refill && !have_h0)) { *what = "queues not sized for this pass"; return hipErrorInvalidValue; }
     buf.region_cap = region_cap_for(cap_paths, rounds);
-#define RUN_AS(B, S, R) return launch_pass<KernelCfg<B, S, R>>(sc, bvh, light_bvh, fr, sum, tab, stream, profiling, form, host_stats, what)
+#define RUN_AS(B, S, R) return launch_pass<KernelCfg<B, S, R>>(sc, bvh, light_bvh, fr, sum, tab, stream, profiling, form, host_stats, dstats, what)
     if (!form.bvh) RUN_AS(false, 0, false);
     if (form.resident) { if (form.share) RUN_AS(true, 1, true); RUN_AS(true, 0, true); }
     if (!form.share) RUN_AS(true, 0, false);

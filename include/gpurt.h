@@ -86,6 +86,7 @@ typedef struct rt_stats {
     uint64_t deferred_probes;   /* light probes of depth 0 that the depth-0 kernel left to the probe kernels (as 112-byte records) */
     uint64_t parked_probes;     /* light probes of depth 0 that the depth-0 kernel wrote as records: those it took up again itself with
                                  * idle lanes of later chunks, and the deferred ones */
+    uint64_t skipped_samples;   /* pixel-samples whose radiance was NaN or infinite and was left out of the sums (option "skip_nonfinite") */
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -208,7 +209,7 @@ int rt_read_srgb8(rt_context *ctx, uint8_t *rgb);
 int rt_get_stats(rt_context *ctx, rt_stats *out);
 int rt_reset_stats(rt_context *ctx);
 
-/* Tuning knobs; unknown names return RT_ERR_INVALID.  None of them changes a result.
+/* Options; unknown names return RT_ERR_INVALID.  None of them changes a result, except "skip_nonfinite" and "tonemap".
  *   "pipeline"      0 = one kernel per sample, one lane per pixel for the whole path;
  *                   1 = staged kernels over compacted ray queues (default)
  *   "batch_samples" samples rendered per pass of the staged pipeline (default 32, at most 512; the queues of a pass
@@ -231,6 +232,11 @@ int rt_reset_stats(rt_context *ctx);
  *                   every path that is still under way (default 2); -1 = every bounce runs staged
  *   "share"         1 = the lanes of a wave share the any-hit searches of its light probes: an idle lane takes a
  *                   subtree off the stack of a busy one (default; needs the hierarchy), 0 = every lane searches alone
+ *   "skip_nonfinite" 1 = a sample whose radiance is NaN or infinite is not added to its pixel's sum (rt_stats.skipped_samples
+ *                   counts them; the sample still counts in n_samples).  0 (default) = it is added, as the reference does
+ *                   (raytracer.glsl:204, sqrt(1 - cos^2) of a rounded cosine above 1, and :274, asin of a direction component
+ *                   beyond 1, yield NaN about once in 10^8 to 10^10 pixel-samples, and the pixel then stays NaN for the rest
+ *                   of the image)
  *   "tonemap"       what rt_read_srgb8 applies: 0 = sRGB transfer (default), 1 = ACES film curve + sRGB transfer
  *   "profiling"     1 = bracket kernels with HIP events and fill the *_ms fields of rt_stats */
 int rt_set_option(rt_context *ctx, const char *name, int64_t value);

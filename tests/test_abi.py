@@ -32,7 +32,7 @@ def test_record_layouts_match_header():
     assert g.TRI_SHADING_DTYPE.itemsize == 100
     assert g.MATERIAL_DTYPE.itemsize == 48
     assert g.TRI_SHADING_DTYPE.fields["normals"][1] == 4 and g.TRI_SHADING_DTYPE.fields["tex_p"][1] == 76
-    assert ctypes.sizeof(api.RtStats) == 176
+    assert ctypes.sizeof(api.RtStats) == 184
 
 
 def test_null_context_is_rejected_without_a_gpu():

@@ -211,3 +211,39 @@ def test_every_path_survives(gpu_ctx, oracle_mod, tmp_path):
     ref, rst = sc.render(CAM, DEFAULT_CLOCK, 6, 1.0, 96, 64, 0, 4)
     img, st = _render(gpu_ctx, 96, 64, 0, 4, pipeline=1, batch=4)
     assert _same_bits(img, ref) and st["rays"] == rst["rays"]
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_skip_nonfinite_option(gpu_ctx, oracle_mod, pipeline):
+    # the opt-in guard: samples whose radiance is NaN or infinite (here: texels that are Inf / NaN) are left out of the sums
+    # and counted; every other sample is added as always
+    from conftest import textured_cubes
+    S = 64
+    (models, shadings, lights, materials), layers, flags = textured_cubes(S, edge_texels=True, nonfinite_texels=True)
+    env = gradient_env()
+    gpu_ctx.upload_scene(models, shadings, lights, materials)
+    gpu_ctx.upload_env(env)
+    gpu_ctx.set_atlas_size(S)
+    for k in (0, 1, 2):
+        gpu_ctx.upload_atlas_layer(2, k, layers[k])
+    gpu_ctx.set_has_texture(flags)
+    try:
+        plain, st = _render(gpu_ctx, 64, 48, 0, 6, clock=31337, pipeline=pipeline, batch=4)
+        assert (~np.isfinite(plain)).any() and st["skipped_samples"] == 0
+        singles = [_render(gpu_ctx, 64, 48, s, 1, clock=31337, pipeline=pipeline)[0] for s in range(6)]
+        gpu_ctx.set_option("skip_nonfinite", 1)
+        guarded, sg = _render(gpu_ctx, 64, 48, 0, 6, clock=31337, pipeline=pipeline, batch=4)
+        assert np.isfinite(guarded).all()
+        want = np.zeros_like(plain)
+        skipped = 0
+        for one in singles:                                   # ascending SAMPLE order, finite samples only
+            ok = np.isfinite(one).all(axis=2)
+            skipped += int((~ok).sum())
+            want = np.where(ok[..., None], (want + one).astype(np.float32), want)
+        assert _same_bits(guarded, want)
+        assert sg["skipped_samples"] == skipped > 0
+        finite = np.isfinite(plain).all(axis=2)
+        assert _same_bits(guarded[finite], plain[finite])
+    finally:
+        gpu_ctx.set_option("skip_nonfinite", 0)
+        gpu_ctx.set_atlas_size(4096)

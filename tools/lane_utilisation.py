@@ -42,7 +42,9 @@ def measure(name, recursion):
     res = {"rays": a["rays"], "probes": a["shadow_probes"] + a["glossy_probes"]}
     for k in ("bvh_extend_nodes", "bvh_extend_tris", "bvh_probe_nodes", "bvh_probe_tris"):
         unit = max(1, a["rays"] if "extend" in k else res["probes"])
-        res[k] = {"per_query": a[k] / unit, "lane_slots_per_query": b[k] / unit, "utilisation": a[k] / max(1, b[k])}
+        res[k] = {"per_query": a[k] / unit, "lane_slots_per_query": b[k] / unit, "utilisation": a[k] / max(1, b[k]),
+                  "steps": a[k], "lane_slots": b[k]}
+    res["pixel_samples"] = a["pixel_samples"]
     return res
 
 

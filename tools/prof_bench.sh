@@ -9,8 +9,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bruteforce-pass --lane-utilisation 0 $@"
-echo "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bruteforce-pass --lane-utilisation 0 $@" > $OUT/command.txt
+ARGS="$R/bench.py --steps 2 --warmup 1 --spp-per-step 512 --no-cpu-baseline --no-bruteforce-pass --lane-utilisation 0 $@"
+echo "python bench.py --steps 2 --warmup 1 --spp-per-step 512 --no-cpu-baseline --no-bruteforce-pass --lane-utilisation 0 $@" > $OUT/command.txt
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT TA_BUSY_avr --output-format csv -d $OUT/pmc_sq2 -- python3 $ARGS > $OUT/pmc_sq2.log 2>&1

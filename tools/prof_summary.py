@@ -13,7 +13,7 @@ base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 try:
     command = open(os.path.join(base, "command.txt")).read().strip()
 except OSError:
-    command = "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bruteforce-pass"
+    command = "python bench.py --steps 2 --warmup 1 --spp-per-step 512 --no-cpu-baseline --no-bruteforce-pass"
 out = ["# rocprofv3 summary '%s': %s\n# (3 passes of 512 spp each at 1920x1080 unless the command says otherwise: 3 launches of "
        "the depth-0 kernel)\n" % (tag, command)]
 def newest(pattern):
