@@ -44,9 +44,9 @@ W, H = 1920, 1080
 SPP_PER_STEP = 4096         # samples of the image per step by default
 SPP_PER_PASS = 512          # samples per pass by default; the counter files under profiles/ are measured with it
 # Vector-instruction issue of gfx950: a SIMD issues a wave64 instruction over 2 clocks (32 lanes per clock; the
-# architectural rate, MI355X_MICROARCH.md).  Measured by tools/microbench_valu.hip (profiles/r03_valu_ceiling.txt), 8
-# waves per SIMD, whole chip: one per 2.32 clocks for v_fma/v_mul/v_add/v_mov/integer add/logic (and for mixes of those
-# with the slower kinds), one per 4.2 clocks for v_min/v_max/v_cmp/v_cndmask/shifts/conversions/packed f32.
+# architectural rate).  Measured by tools/microbench_valu.hip (profiles/r03_valu_ceiling.txt), 8 waves per SIMD, whole
+# chip: one per 2.32 clocks for v_fma/v_mul/v_add/v_mov/integer add/logic (and for even mixes of those with the slower
+# kinds), one per 4.2 clocks for v_min/v_max/v_cmp/v_cndmask/shifts/conversions/packed f32 on their own.
 VALU_ARCH_CLOCKS = 2.0
 VALU_FAST_CLOCKS = 2.32
 VALU_SLOW_CLOCKS = 4.2
@@ -401,9 +401,9 @@ def main():
                               "clocks_per_instruction_and_simd": SIMDS * CLOCK_HZ / (rate * 1e9),
                               "wave_insts_per_launch": prof["valu_wave_insts"],
                               "peak_source": "architectural: a wave64 instruction issues over %.0f clocks on a SIMD, 1024 SIMDs, 2.4 GHz; "
-                                             "measured on this chip (profiles/r03_valu_ceiling.txt): %.2f clocks for fma/mul/add/mov/"
-                                             "integer add/logic, %.1f for min/max/compare/select/shift/convert, so a loop that is "
-                                             "40 %% of the slow kind cannot issue faster than one per 3.1 clocks"
+                                             "measured on this chip with 8 waves per SIMD (profiles/r03_valu_ceiling.txt): %.2f clocks for fma/mul/add/mov/"
+                                             "integer add/logic and for even mixes of those with the other kinds, %.1f for "
+                                             "min/max/compare/select/shift/convert on their own"
                                              % (VALU_ARCH_CLOCKS, VALU_FAST_CLOCKS, VALU_SLOW_CLOCKS),
                               "insts_source": provenance}
             # Useful work: the vector lane-operations the algorithm needs (node steps and triangle tests of every lane's own

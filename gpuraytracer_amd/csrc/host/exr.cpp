@@ -376,7 +376,23 @@ bool writeEXR(const std::string &path, int width, int height, int channels, cons
     return true;
 }
 
+static bool readEXRBody(const std::string &path, int &width, int &height, std::vector<float> &rgba, std::string *err);
+
+// No exception leaves this function: a damaged file (or one too large for the memory at hand) is a `false` with a message,
+// also for the callers that are not behind the C entry points (Scene::loadMaterial, Scene::loadEnvironmentTexture).
 bool readEXR(const std::string &path, int &width, int &height, std::vector<float> &rgba, std::string *err) {
+    try {
+        return readEXRBody(path, width, height, rgba, err);
+    } catch (const std::exception &e) {
+        if (err) *err = "readEXR: " + std::string(e.what()) + " (" + path + ")";
+    } catch (...) {
+        if (err) *err = "readEXR: failed (" + path + ")";
+    }
+    rgba.clear();
+    return false;
+}
+
+static bool readEXRBody(const std::string &path, int &width, int &height, std::vector<float> &rgba, std::string *err) {
     auto fail = [&](const std::string &m) { if (err) *err = "readEXR: " + m + " (" + path + ")"; return false; };
     std::ifstream f(path, std::ios::binary);
     if (!f) return fail("cannot open");
@@ -404,9 +420,11 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
                 c.type = (int)a.u32();
                 a.u32();                        // pLinear + reserved
                 const uint32_t xs = a.u32(), ys = a.u32();
+                if (!a.ok) return fail("truncated channel list");
                 if (xs != 1 || ys != 1) return fail("subsampled channels are not supported");
                 chans.push_back(c);
             }
+            if (!a.ok) return fail("truncated channel list");
         } else if (name == "compression") {
             compression = size ? (int)*a.p : -1;
         } else if (name == "dataWindow") {
@@ -420,6 +438,7 @@ bool readEXR(const std::string &path, int &width, int &height, std::vector<float
     if (!r.ok || chans.empty() || xmax < xmin || ymax < ymin) return fail("bad header");
     if (compression < 0 || compression > 4) return fail("compression must be NONE, RLE, ZIPS, ZIP or PIZ");
     if (tiled && (tile_w == 0 || tile_h == 0)) return fail("tiled file without a tile description");
+    if (tiled && (tile_w > 65536u || tile_h > 65536u)) return fail("tile size above 65536");
     if (tiled && (tile_mode & 0xFu) > 2) return fail("bad level mode in the tile description");
     const int64_t wide = (int64_t)xmax - xmin + 1, high = (int64_t)ymax - ymin + 1;
     if (wide > 65536 || high > 65536 || wide * high > ((int64_t)1 << 28)) return fail("data window above 2^28 pixels");

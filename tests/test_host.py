@@ -437,6 +437,33 @@ def test_exr_reader_refuses_absurd_headers(tmp_path):
             host.read_exr(p)
 
 
+def test_exr_reader_refuses_huge_tiles_and_truncated_channel_lists(tmp_path):
+    # a tile size of 2^31 or more would turn negative in the block arithmetic; a channel list that ends in the middle of a
+    # channel would leave a channel with made-up fields: both are refused with a message, no exception, no crash
+    rng = np.random.default_rng(8)
+    img = rng.uniform(0, 1, size=(20, 24, 3)).astype(np.float32)
+    p = str(tmp_path / "t.exr")
+    _tiled_exr(p, img, 16, 16, 0)
+    raw = bytearray(open(p, "rb").read())
+    at = raw.index(b"tiles\0tiledesc\0") + len(b"tiles\0tiledesc\0") + 4
+    for tw, th in ((2 ** 31, 16), (16, 2 ** 32 - 1), (2 ** 31 + 5, 2 ** 31 + 5), (70000, 16)):
+        raw[at:at + 8] = struct.pack("<II", tw, th)
+        open(p, "wb").write(bytes(raw))
+        with pytest.raises(IOError):
+            host.read_exr(p)
+    q = str(tmp_path / "c.exr")
+    _plain_exr(q, {"R": img[..., 0], "G": img[..., 1], "B": img[..., 2]})
+    raw = bytearray(open(q, "rb").read())
+    at = raw.index(b"channels\0chlist\0") + len(b"channels\0chlist\0")
+    size = struct.unpack("<I", raw[at:at + 4])[0]
+    # the list loses its last 9 bytes (the end marker and half of the last channel) but keeps its place in the file
+    raw[at:at + 4] = struct.pack("<I", size - 9)
+    cut = bytes(raw[:at + 4 + size - 9]) + bytes(raw[at + 4 + size:])
+    open(q, "wb").write(cut)
+    with pytest.raises(IOError):
+        host.read_exr(q)
+
+
 def _plain_exr(path, planes):
     """An uncompressed FLOAT scanline file of the given channels ({name: [h, w] float32})."""
     names = sorted(planes)

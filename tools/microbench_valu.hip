@@ -178,11 +178,16 @@ int main(int argc, char **argv) {
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("# %s, %d CUs; %d loop iterations x 64 instructions per wave\n", prop.gcnArchName, cus, iters);
-    printf("# w = waves per SIMD (4 SIMDs per CU, every CU loaded); cycles = s_memtime ticks, median over all waves\n");
-    printf("# span = first wave's start to last wave's end (s_memrealtime, 100 MHz); 'SIMDs' = distinct (XCC, SE, CU, SIMD) ids the waves report,\n"
-           "# 'w seen' = largest number of waves whose loops overlap in time on one SIMD\n");
-    printf("%-30s %2s %18s %18s %10s %16s %14s %10s %6s %7s %22s\n", "instruction", "w", "cyc/inst (1 wave)", "cyc/inst per SIMD", "clock MHz",
-           "G wave-inst/s", "T lane-op/s", "span ms", "SIMDs", "w seen", "span: cyc/inst per SIMD");
+    printf("# w = waves per SIMD (4 SIMDs per CU, every CU loaded)\n");
+    printf("# cyc/inst per SIMD = all instructions of the launch over the time from the first wave's start to the last wave's end\n"
+           "#   (s_memrealtime, 100 MHz), in shader clocks (clock = s_memtime ticks per s_memrealtime tick of the median wave: s_memtime\n"
+           "#   counts shader clocks on gfx950), per SIMD.  This is the rate a SIMD sustains; the rates in the next columns follow from it.\n"
+           "# one wave's cyc/inst = s_memtime ticks the median wave spent per instruction of its own loop.  It is NOT w times the figure\n"
+           "#   before: the waves of a SIMD do not share its issue slots evenly for the whole of their loops (the oldest wave is served\n"
+           "#   first and ends early, younger ones end late), so dividing one wave's time by w overstates what the SIMD issues.\n"
+           "# 'SIMDs' = distinct (XCC, SE, CU, SIMD) ids the waves report, 'w seen' = largest number of waves whose loops overlap on one SIMD\n");
+    printf("%-30s %2s %20s %10s %16s %14s %10s %6s %7s %22s\n", "instruction", "w", "cyc/inst per SIMD", "clock MHz",
+           "G wave-inst/s", "T lane-op/s", "span ms", "SIMDs", "w seen", "one wave's cyc/inst");
     Stamp *d_out;
     float *d_sink;
     const int max_waves = cus * 32;
@@ -210,8 +215,7 @@ int main(int argc, char **argv) {
             std::sort(cyc.begin(), cyc.end());
             std::sort(mhz.begin(), mhz.end());
             const double c = cyc[n_waves / 2], f = mhz[n_waves / 2];
-            const double per_simd = c / w;
-            const double rate = 4.0 * cus * f * 1e6 / per_simd;      // wave-instructions per second, whole chip
+
             // whole-launch view: all instructions over the time from the first start to the last end
             unsigned long long first = ~0ull, last = 0;
             std::map<unsigned long long, std::vector<std::pair<unsigned long long, int>>> per_simd_events;
@@ -232,8 +236,9 @@ int main(int argc, char **argv) {
             const double span_s = (double)(last - first) / 100e6;
             const double total_inst = (double)n_waves * iters * 64.0;
             const double span_cyc_per_inst_simd = span_s * f * 1e6 * 4.0 * cus / total_inst;
-            printf("%-30s %2d %18.3f %18.3f %10.0f %16.1f %14.2f %10.3f %6zu %7d %22.3f\n", names[kind], w, c, per_simd, f, rate / 1e9,
-                   rate * 64.0 * lane_ops[kind] / 1e12, span_s * 1e3, per_simd_events.size(), w_seen, span_cyc_per_inst_simd);
+            const double rate = total_inst / span_s;                 // wave-instructions per second, whole chip
+            printf("%-30s %2d %20.3f %10.0f %16.1f %14.2f %10.3f %6zu %7d %22.3f\n", names[kind], w, span_cyc_per_inst_simd, f, rate / 1e9,
+                   rate * 64.0 * lane_ops[kind] / 1e12, span_s * 1e3, per_simd_events.size(), w_seen, c);
         }
     }
     return 0;
