@@ -83,6 +83,12 @@ struct rt_context {
     int refill = -1;           // -1 auto (lane refill from REFILL_AUTO_MIN triangles on), 0 off, 1 on
     int skip_nonfinite = 0;    // 1: samples whose radiance is NaN or infinite are left out of the sums and counted
 
+    // candidate lists of the camera rays (k_build_tile_lists): one per 8x8 tile of the selected target, for the frame set last
+    uint32_t *d_tile_lists = nullptr;
+    size_t tile_lists_cap = 0;     // tiles the buffer holds
+    bool tile_lists_valid = false;
+    int tile_lists = -1;           // option: -1 auto (scenes of up to TILE_LIST_MAX_TRIANGLES triangles), 0 never
+
     // stats
     DStats *d_stats = nullptr;
     rt_stats host_stats;
@@ -337,6 +343,7 @@ int rt_destroy(rt_context *ctx) {
     if (ctx->d_sum_own) (void)hipFree(ctx->d_sum_own);
     if (ctx->parked.d_sum_own) (void)hipFree(ctx->parked.d_sum_own);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_tile_lists) (void)hipFree(ctx->d_tile_lists);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -376,6 +383,7 @@ int rt_upload_scene(rt_context *ctx, const rt_triangle_model *models, const rt_t
     if (bind_device(ctx)) return RT_ERR_DEVICE;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
+    ctx->tile_lists_valid = false;
 
     // geometry: the 48-byte record as is (3 x float4); shading: 7 float4 planes
     std::vector<float4> shade((size_t)7 * count);
@@ -535,6 +543,7 @@ int rt_resize(rt_context *ctx, uint32_t width, uint32_t height) {
     ctx->width = width;
     ctx->height = height;
     ctx->n_samples = 0;
+    ctx->tile_lists_valid = false;
     memset(&ctx->host_stats, 0, sizeof(ctx->host_stats));
     ctx->staged_paths_expected = 0;
     return RT_OK;
@@ -554,6 +563,7 @@ int rt_select_target(rt_context *ctx, int target) {
     ctx->n_samples = ctx->parked.n_samples;
     ctx->parked = now;
     ctx->target = target;
+    ctx->tile_lists_valid = false;
     return RT_OK;
 }
 
@@ -617,6 +627,7 @@ int rt_set_frame(rt_context *ctx, const float camera[16], uint32_t clock, int32_
     ctx->frame.exposure = exposure;
     ctx->have_frame = true;
     ctx->chain_valid = false;
+    ctx->tile_lists_valid = false;
     return RT_OK;
 }
 
@@ -647,6 +658,28 @@ int rt_trace(rt_context *ctx, uint32_t sample_begin, uint32_t sample_count, uint
     form.share = acc && ctx->share != 0;
     form.refill = acc && (ctx->refill < 0 ? ctx->count >= REFILL_AUTO_MIN : ctx->refill != 0);
     form.staged_depths = ctx->staged_depths;
+    form.lists.lists = nullptr;
+    form.lists.enabled = 0;
+    if (ctx->pipeline != 0 && acc && ctx->tile_lists != 0 && ctx->count <= TILE_LIST_MAX_TRIANGLES) {
+        // candidate lists of the camera rays, rebuilt when the camera, the target or the scene has changed
+        const uint32_t tiles_x = (ctx->width + 7u) >> 3, tiles_y = (ctx->height + 7u) >> 3;
+        const size_t tiles = (size_t)tiles_x * tiles_y;
+        if (tiles > ctx->tile_lists_cap) {
+            if (ctx->d_tile_lists) (void)hipFree(ctx->d_tile_lists);
+            ctx->d_tile_lists = nullptr;
+            ctx->tile_lists_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_tile_lists, tiles * TILE_LIST_WORDS * sizeof(uint32_t)));
+            ctx->tile_lists_cap = tiles;
+            ctx->tile_lists_valid = false;
+        }
+        if (!ctx->tile_lists_valid) {
+            hipLaunchKernelGGL(k_build_tile_lists, dim3((unsigned)tiles), dim3(64), 0, ctx->stream, sc, ctx->frame, tiles_x, tiles_y, ctx->d_tile_lists);
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->tile_lists_valid = true;
+        }
+        form.lists.lists = ctx->d_tile_lists;
+        form.lists.enabled = 1;
+    }
     if (ctx->pipeline != 0) {
         // The queues of a pass hold 1/queue_rounds of the case that every path survives every bounce (a pass that needs
         // more takes more rounds); fewer samples per pass if that does not fit the free device memory (the image does
@@ -902,6 +935,8 @@ int rt_set_option(rt_context *ctx, const char *name, int64_t value) {
     } else if (!strcmp(name, "tonemap")) {
         if (value != 0 && value != 1) return fail(ctx, RT_ERR_INVALID, "tonemap must be 0 or 1");
         ctx->tonemap = (int)value;
+    } else if (!strcmp(name, "tile_lists")) {
+        ctx->tile_lists = value < 0 ? -1 : (value ? 1 : 0);
     } else if (!strcmp(name, "skip_nonfinite")) {
         ctx->skip_nonfinite = value ? 1 : 0;
     } else if (!strcmp(name, "share")) {

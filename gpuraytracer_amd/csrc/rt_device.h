@@ -340,6 +340,15 @@ RT_DEV uint32_t pixel_seed(const DFrame &fr, uint32_t tx, uint32_t ty, uint32_t 
     return fr.clock + (tx * fr.height + ty + 394587u) * (sample + 1u) * 13u + sample;    // :594
 }
 
+// Origin of every camera ray: CAMERA * (0, 0, 0, 1) as the shader's matrix product evaluates it (raytracer.glsl:604).
+RT_DEV f3 camera_origin(const DFrame &fr) {
+    const float *M = fr.cam;
+    float o4[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) o4[r] = ((M[0 + r] * 0.0f + M[4 + r] * 0.0f) + M[8 + r] * 0.0f) + M[12 + r] * 1.0f;
+    return mk3(o4[0], o4[1], o4[2]);
+}
+
 RT_DEV Ray camera_ray(const DFrame &fr, uint32_t tx, uint32_t ty, uint32_t &seed) {
     const float W = (float)fr.width, H = (float)fr.height;
     const float inv_width = 1.0f / W, inv_height = 1.0f / H;

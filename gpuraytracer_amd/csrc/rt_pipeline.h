@@ -509,6 +509,132 @@ RT_DEV void store_route_fill(const PipeBuffers &b, int q_in, const RouteFill &fi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Candidate lists of the camera rays.  All camera rays of a frame start at one point, and the rays of one 8x8 pixel
+// tile (every SAMPLE of it: the jitter stays inside the pixel) lie in a narrow pyramid.  Once per frame, for every tile,
+// the triangles that pyramid can touch are listed (k_build_tile_lists); the depth-0 kernel then folds a camera ray
+// over its tile's list in ascending triangle index with the shader's own test (closest_hit_list), which is the
+// reference's loop (raytracer.glsl:217-235) with the triangles left out that cannot pass its test for any ray of the
+// tile: same result, bit for bit, without a hierarchy traversal.  The list of a wave's tile is wave-uniform, so ids
+// and triangle records come through scalar loads.
+//   A triangle is left out only if (a) its plane distance `relative_depth` (raytracer.glsl:137, the same expression on the
+//   same values for every camera ray) is <= 0, which the shader rejects, or (b) its three corners lie outside one of the four
+//   side planes of the tile's pyramid, widened by a quarter pixel and tested with a relative margin of 1e-4.
+// A list holds up to TILE_LIST_CAP triangles; a tile that would need more keeps the hierarchy (count 0xFFFF), and so do
+// frames whose camera matrix is not finite.  Rays that are not finite take the loop over all triangles, where every
+// comparison being false makes the last triangle win.
+constexpr uint32_t TILE_LIST_CAP = 31;            // 16 words per tile: count and up to 31 triangle ids, 16 bits each
+constexpr uint32_t TILE_LIST_WORDS = 16;
+constexpr uint32_t TILE_LIST_OVERFLOW = 0xFFFFu;
+constexpr int TILE_LIST_MAX_TRIANGLES = 16384;    // scenes beyond this keep the hierarchy for their camera rays
+struct DTileLists { const uint32_t *lists; int enabled; };
+
+__global__ __launch_bounds__(64) void k_build_tile_lists(DScene sc, DFrame fr, uint32_t tiles_x, uint32_t tiles_y,
+                                                         uint32_t *__restrict__ lists) {
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    __shared__ uint32_t ids[TILE_LIST_CAP + 1];
+    uint32_t tile_x, tile_y;
+    tile_position(tile, tiles_x, tiles_y, tile_x, tile_y);
+    const float W = (float)fr.width, H = (float)fr.height;
+    const float inv_h = 1.0f / H, inv_w = 1.0f / W, margin = 0.25f * inv_h;
+    // the camera-space directions (a, b, 1/2) of the tile's rays before they are normalised (raytracer.glsl:602)
+    const float a0 = ((float)(int)(tile_x * 8u) - 0.5f * W + 0.5f) * inv_h - margin;
+    const float a1 = ((float)(int)(tile_x * 8u + 7u) - 0.5f * W + 0.5f) * inv_h + inv_w + margin;
+    const float b0 = ((float)(int)(tile_y * 8u) + 0.5f) * inv_h - 0.5f - margin;
+    const float b1 = ((float)(int)(tile_y * 8u + 7u) + 0.5f) * inv_h - 0.5f + inv_h + margin;
+    const float *M = fr.cam;
+    auto world = [&](float a, float b) {
+        return mk3((M[0] * a + M[4] * b) + M[8] * 0.5f, (M[1] * a + M[5] * b) + M[9] * 0.5f, (M[2] * a + M[6] * b) + M[10] * 0.5f);
+    };
+    const f3 c0 = world(a0, b0), c1 = world(a1, b0), c2 = world(a1, b1), c3 = world(a0, b1);
+    const f3 mid = world(0.5f * (a0 + a1), 0.5f * (b0 + b1));
+    const f3 o = camera_origin(fr);
+    const float check = (((o.x + o.y) + o.z) + ((c0.x + c0.y) + c0.z)) + (((c2.x + c2.y) + c2.z) + ((c1.x + c3.x) + (c1.y + c3.y)) + (c1.z + c3.z));
+    bool usable = (check - check) == 0.0f;          // no NaN, no infinity
+    // side planes through the origin, normals pointing inwards (towards the middle ray); a plane that does not tell the
+    // middle ray from the outside (a matrix that flattens the pyramid) is not used
+    f3 n[4] = {cross(c0, c1), cross(c1, c2), cross(c2, c3), cross(c3, c0)};
+    float nl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float s = dot(n[k], mid);
+        if (s < 0.0f) n[k] = mk3(-n[k].x, -n[k].y, -n[k].z);
+        if (!(s != 0.0f)) n[k] = mk3(0.0f, 0.0f, 0.0f);
+        nl[k] = length(n[k]);
+    }
+    uint32_t count = 0;
+    for (int base = 0; usable && base < sc.count && count <= TILE_LIST_CAP; base += 64) {
+        const int i = base + (int)lane;
+        bool keep = false;
+        if (i < sc.count) {
+            const float4 *g = sc.geo + 3 * (size_t)i;
+            const float4 qa = g[0], qb = g[1], qc = g[2];
+            const f3 tn = mk3(qa.x, qa.y, qa.z), tp = mk3(qa.w, qb.x, qb.y), tu = mk3(qb.z, qb.w, qc.x), tv = mk3(qc.y, qc.z, qc.w);
+            // (a) relative_depth of intersectTriangle, the same value for every camera ray
+            const f3 delta = o - tp;
+            const float rd = dot(tn, delta);
+            keep = !(rd <= 0.0f);
+            // (b) all three corners outside one side plane
+            const f3 v0 = tp - o, v1 = (tp + tu) - o, v2 = (tp + tv) - o;
+            const float l0 = length(v0), l1 = length(v1), l2 = length(v2);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float t = 1e-4f * nl[k];
+                const bool out = (dot(n[k], v0) < -t * l0) & (dot(n[k], v1) < -t * l1) & (dot(n[k], v2) < -t * l2);
+                keep = keep & !out;
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (keep && count + rank < TILE_LIST_CAP) ids[1u + count + rank] = (uint32_t)i;      // ascending: lanes and rounds both ascend
+        count += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    const uint32_t header = (usable && count <= TILE_LIST_CAP) ? count : TILE_LIST_OVERFLOW;
+    if (lane < TILE_LIST_WORDS) {
+        const uint32_t k0 = 2u * lane, k1 = 2u * lane + 1u;
+        const uint32_t h0 = k0 == 0u ? header : (k0 <= count && count <= TILE_LIST_CAP ? ids[k0] : 0u);
+        const uint32_t h1 = (k1 <= count && count <= TILE_LIST_CAP) ? ids[k1] : 0u;
+        lists[(size_t)tile * TILE_LIST_WORDS + lane] = (h0 & 0xFFFFu) | (h1 << 16);
+    }
+}
+
+// findIntersection (raytracer.glsl:217-235) over the `n` triangles of a tile's list (ids[1..n], 16 bits each, ascending).
+// `ids` is wave-uniform.  Returns the triangle id (-1 = miss); isec as the fold leaves it.
+// The ids and the triangle records come through scalar loads (the index is wave-uniform).  Asking for the next round's
+// record before the current one is tested was tried and gained nothing: the other waves of the SIMD cover the wait.
+RT_DEV int closest_hit_list(const DScene &sc, const uint32_t *ids, uint32_t n, const Ray &ray, bool active, f4 &isec) {
+    typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+    const const_u32_ptr w = (const_u32_ptr)ids;
+    isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 1.0f;
+    int best = -1;
+    const float s = ((ray.o.x + ray.o.y) + ray.o.z) + ((ray.d.x + ray.d.y) + ray.d.z);
+    const bool finite = (s - s) == 0.0f;
+    const bool run = active & finite;
+    for (uint32_t k = 1; k <= n; k++) {
+        const int i = (int)((w[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu);
+        const Tri t = load_tri(sc.geo, i);
+        PlaneTest pt;
+        const bool p = run & plane_test_closest(ray, t, isec, pt);
+        if (__builtin_amdgcn_ballot_w64(p) != 0ull) {
+            float rx, ry;
+            if (p & inside_test(ray, t, pt, rx, ry)) {
+                isec.x = rx; isec.y = ry; isec.z = pt.rd; isec.w = pt.det;
+                best = i;
+            }
+        }
+    }
+    // a ray that is not finite passes every rejection of the shader's test: it needs all triangles, in order
+    const bool redo = active & !finite;
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+        f4 s2;
+        s2.x = 0.0f; s2.y = 0.0f; s2.z = -1.0f; s2.w = 1.0f;
+        const int b2 = closest_hit_range(sc.geo, 0, sc.count, ray, redo, -1, s2, -1);
+        if (redo) { isec = s2; best = b2; }
+    }
+    return best;
+}
+
 // Camera path of queue position `qi` at depth 0 (raytracer.glsl:586-607); `sample` is the SAMPLE of its slot.
 // Returns false for the padding lanes of ragged tiles.
 RT_DEV bool first_path(const DFrame &fr, uint32_t sample, uint32_t in_sample, uint32_t tiles_x, bool live, PathState &ps) {
@@ -730,7 +856,7 @@ constexpr int LARGE_SCENE_TRIANGLES = 65536;     // from here on the whole depth
 template <class CFG, bool LATER>
 __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void k_first(DScene sc, DBvh bv, DBvh lbv, DFrame fr, PipeBuffers b,
                                                                               PassTables tab, uint32_t paths_per_sample,
-                                                                              int max_depth) {
+                                                                              int max_depth, DTileLists tl) {
     if (LATER && round_is_idle(b.work, b.round)) return;
     const uint32_t lane = lane_index(), wave = wave_index();
     const uint32_t total = paths_per_sample * tab.n;
@@ -856,7 +982,16 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         n_paths += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live));
         Ray ray; ray.o = ps.o; ray.d = ps.d;
         f4 isec;
-        const int hit = closest_hit_cfg<CFG>(sc, bv, ray, live, ws, isec, bc);
+        int hit;
+        // the tile's candidate list if it has one, else the hierarchy (or the loop over all triangles)
+        const uint32_t *list = tl.lists + (size_t)tile_of_chunk * TILE_LIST_WORDS;
+        const uint32_t listed = (CFG::BVH && tl.enabled) ? (*(const __attribute__((address_space(4))) uint32_t *)list & 0xFFFFu) : TILE_LIST_OVERFLOW;
+#if RT_PROBE_HISTO == 3
+        // measurement build: chunks by the length of their tile's candidate list (up to 4, 5-12, 13-31, none: hierarchy)
+        histo[listed == TILE_LIST_OVERFLOW ? 3u : (listed <= 4u ? 0u : (listed <= 12u ? 1u : 2u))]++;
+#endif
+        if (listed != TILE_LIST_OVERFLOW) hit = closest_hit_list(sc, list, listed, ray, live, isec);
+        else hit = closest_hit_cfg<CFG>(sc, bv, ray, live, ws, isec, bc);
         SECTION_MARK(0);
         const float inv_det = 1.0f / isec.w;
         uint32_t ls = tab.light_seed[slot];
@@ -942,7 +1077,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         const bool run = (wants && !parked) || host;
 #if RT_PROBE_HISTO > 0
         // measurement build: searches of the depth-0 kernel by the number of lanes they run with (1: shadow, 2: glossy)
-        if ((RT_PROBE_HISTO == 1) == coin_diffuse) {
+        if (RT_PROBE_HISTO < 3 && (RT_PROBE_HISTO == 1) == coin_diffuse) {
             const uint32_t n_run = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(run));
             if (n_run) histo[n_run < 48u ? n_run / 16u : 3u]++;
         }
@@ -1434,6 +1569,7 @@ struct PassForm {
     bool share;          // shared any-hit searches
     bool refill;         // lane-refill form of the extend stage
     int staged_depths;   // bounces after the first that run as staged kernels before the tail kernel takes the rest; < 0: all
+    DTileLists lists;    // candidate lists of the camera rays (k_build_tile_lists), or not enabled
 };
 
 // pcgHash (raytracer.glsl:89-94) on the host, for the tables of a pass.
@@ -1650,8 +1786,8 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
         buf.defer_below = (CFG::BVH && sc.count < DEFER_MAX_TRIANGLES) ? DEFER_BELOW : 0u;
         buf.dynamic_share = (CFG::BVH && sc.count >= LARGE_SCENE_TRIANGLES) ? DYNAMIC_SHARE_LARGE : DYNAMIC_SHARE;
         PIPE_TRY(stamp(round == 0 ? 3 : 4));
-        if (round == 0) hipLaunchKernelGGL((k_first<CFG, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
-        else hipLaunchKernelGGL((k_first<CFG, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth);
+        if (round == 0) hipLaunchKernelGGL((k_first<CFG, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth, form.lists);
+        else hipLaunchKernelGGL((k_first<CFG, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth, form.lists);
         PIPE_TRY(hipGetLastError());
         if (buf.defer_below) {
             // the probes that k_first left to the probe stages (chunks with few of them); survivors join queue 1

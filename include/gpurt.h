@@ -232,6 +232,9 @@ int rt_reset_stats(rt_context *ctx);
  *                   every path that is still under way (default 2); -1 = every bounce runs staged
  *   "share"         1 = the lanes of a wave share the any-hit searches of its light probes: an idle lane takes a
  *                   subtree off the stack of a busy one (default; needs the hierarchy), 0 = every lane searches alone
+ *   "tile_lists"    -1 = for scenes of up to 16384 triangles the camera rays of an 8x8 pixel tile are tested against a list
+ *                   of the triangles that tile's rays can touch, made once per frame, instead of searching the hierarchy
+ *                   (default; needs the hierarchy for the tiles whose lists would be too long), 0 = never
  *   "skip_nonfinite" 1 = a sample whose radiance is NaN or infinite is not added to its pixel's sum (rt_stats.skipped_samples
  *                   counts them; the sample still counts in n_samples).  0 (default) = it is added, as the reference does
  *                   (raytracer.glsl:204, sqrt(1 - cos^2) of a rounded cosine above 1, and :274, asin of a direction component

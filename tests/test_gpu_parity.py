@@ -31,14 +31,16 @@ def _upload(ctx, scene, env):
 #                                                       itself from 65536 triangles on, the other forms keep it off)
 #   5 staged, tail kernel right after depth 0         6 staged, hierarchy never resident in LDS
 #   7 staged, every lane searches alone (no sharing)  8 staged, loops over all triangles, every bounce staged
-FORMS = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+#   9 staged, library defaults but camera rays through the hierarchy (no candidate lists per tile)
+FORMS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
 
 
 def _render(ctx, w, h, begin, count, stride=1, recursion=6, clock=DEFAULT_CLOCK, pipeline=1, batch=4, cam=CAM, exposure=1.0,
             rounds=3):
     ctx.set_option("queue_rounds", rounds)
     ctx.set_option("accel", 0 if pipeline in (3, 8) else 1)
-    ctx.set_option("refill", 1 if pipeline == 4 else (-1 if pipeline == 1 else 0))
+    ctx.set_option("refill", 1 if pipeline == 4 else (-1 if pipeline in (1, 9) else 0))
+    ctx.set_option("tile_lists", 0 if pipeline == 9 else -1)
     ctx.set_option("staged_depths", -1 if pipeline in (2, 8) else (0 if pipeline == 5 else 2))
     ctx.set_option("resident", 0 if pipeline == 6 else -1)
     ctx.set_option("share", 0 if pipeline == 7 else 1)
@@ -428,7 +430,7 @@ def test_textured_materials_bit_exact(gpu_ctx, oracle_mod, case):
         target.set_has_texture(flags)
     clock, recursion = int(g["clock"]), int(g["recursion"])
     want, wst = sc.render(g["camera"], clock, recursion, 1.0, 48, 32, 0, 4)
-    for pipeline in (0, 1, 3, 4, 5, 6):
+    for pipeline in (0, 1, 3, 4, 5, 6, 9):
         img, st = _render(gpu_ctx, 48, 32, 0, 4, clock=clock, recursion=recursion, pipeline=pipeline, cam=g["camera"])
         assert np.array_equal(img, want, equal_nan=True), (pipeline, float(np.nanmax(np.abs(img - want))))
         assert st["rays"] == wst["rays"]
@@ -536,7 +538,7 @@ def test_random_soups(gpu_ctx, oracle_mod, tmp_path, seed):
     cam = camera_matrix((0.2, 0.4, -4.5), (-0.1, 0.05))
     want, wst = sc.render(cam, 1000 + seed, 8, 1.0, 72, 56, 0, 5)
     assert wst["rays"] > 1.05 * wst["pixel_samples"] and wst["shadow_probes"] > 500 and wst["glossy_probes"] > 500
-    for pipeline in (0, 1, 2, 3, 4, 5, 7):
+    for pipeline in (0, 1, 2, 3, 4, 5, 7, 9):
         img, st = _render(gpu_ctx, 72, 56, 0, 5, recursion=8, clock=1000 + seed, pipeline=pipeline, batch=2, cam=cam)
         same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
         assert same.all(), (seed, pipeline, int((~same).sum()))
@@ -602,7 +604,7 @@ def test_axis_parallel_render(gpu_ctx, oracle_mod, tmp_path, name, zero_row):
     sc.upload_env(env)
     want, wst = sc.render(cam, 4242, 6, 1.0, 64, 48, 0, 4)
     assert wst["rays"] > wst["pixel_samples"]
-    for pipeline in (1, 3, 5, 6, 7):
+    for pipeline in (1, 3, 5, 6, 7, 9):
         img, st = _render(gpu_ctx, 64, 48, 0, 4, recursion=6, clock=4242, pipeline=pipeline, batch=2, cam=cam)
         same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
         assert same.all(), (pipeline, int((~same).sum()))
@@ -619,7 +621,7 @@ def test_soak_findings(gpu_ctx, tmp_path, seed):
     scene, cam, w, h, spp, rec, clock, batches = soak_parity.case_for(seed, str(tmp_path), _write_soup)
     _upload(gpu_ctx, scene, gradient_env())
     want, wst = _render(gpu_ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=3, cam=cam)
-    for pipeline in (1, 5, 7):
+    for pipeline in (1, 5, 7, 9):
         img, st = _render(gpu_ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=pipeline, cam=cam)
         same = (img.view(np.uint32) == want.view(np.uint32)) | (np.isnan(img) & np.isnan(want))
         assert same.all(), (pipeline, int((~same).sum()))

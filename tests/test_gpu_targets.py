@@ -247,3 +247,57 @@ def test_skip_nonfinite_option(gpu_ctx, oracle_mod, pipeline):
     finally:
         gpu_ctx.set_option("skip_nonfinite", 0)
         gpu_ctx.set_atlas_size(4096)
+
+
+@pytest.mark.parametrize("name", ["cubes", "_ObiWan"])
+def test_tile_candidate_lists_with_odd_cameras(gpu_ctx, oracle_mod, name):
+    # The candidate lists of the camera rays (one per 8x8 tile, made once per frame) against the hierarchy (form 9) and the
+    # loop over all triangles (form 3), bit for bit, for camera matrices that are nobody's idea of a camera: mirrored, scaled
+    # by 1000 and by 1/1000, sheared, a zero column, a zero matrix, a NaN entry, an origin inside the geometry, a camera
+    # that looks away from everything; and on targets that are not a whole number of tiles.
+    scene = load_scene(name)
+    _upload(gpu_ctx, scene, gradient_env())
+    rng = np.random.default_rng(77)
+    base = camera_matrix((0.2, 1.1, -2.4), (-0.5, 0.3))
+    cams = [base]
+    m = base.copy(); m[0:3] *= -1.0; cams.append(m)                                   # mirrored x axis
+    m = base.copy(); m[0:12] *= 1000.0; cams.append(m)                                # scaled up
+    m = base.copy(); m[0:12] *= 0.001; cams.append(m)                                 # scaled down
+    m = base.copy(); m[4:7] += 0.7 * m[0:3]; cams.append(m)                           # sheared
+    m = base.copy(); m[8:11] *= 0.05; cams.append(m)                                  # very wide field of view
+    m = base.copy(); m[8:11] *= 40.0; cams.append(m)                                  # very narrow one
+    m = base.copy(); m[4:8] = 0.0; cams.append(m)                                     # zero column: all rays in a plane
+    m = np.zeros(16, np.float32); m[12:16] = (0.0, 1.0, -2.0, 1.0); cams.append(m)    # zero directions
+    m = base.copy(); m[5] = np.nan; cams.append(m)                                    # NaN in the rotation
+    m = base.copy(); m[13] = np.inf; cams.append(m)                                   # origin at infinity
+    m = base.copy(); m[12:15] = (0.0, 0.0, 0.0); cams.append(m)                       # origin on the floor plane / inside
+    cams.append(camera_matrix((0.0, 1.5, -3.0), (0.9, 3.1)))                          # looks away
+    for _ in range(6):
+        m = camera_matrix(tuple(rng.uniform([-2, 0.1, -4], [2, 3, 1])), tuple(rng.uniform([-1.2, -3.2], [0.6, 3.2])))
+        m[0:12] += rng.normal(0, 0.15, 12).astype(np.float32)
+        cams.append(m)
+    sizes = [(64, 48), (61, 35), (8, 8), (9, 17), (200, 3)]
+    for k, cam in enumerate(cams):
+        w, h = sizes[k % len(sizes)]
+        want, wst = _render(gpu_ctx, w, h, 0, 3, clock=1000 + k, pipeline=3, batch=2, cam=cam)
+        for pipeline in (1, 9, 5):
+            img, st = _render(gpu_ctx, w, h, 0, 3, clock=1000 + k, pipeline=pipeline, batch=2, cam=cam)
+            assert _same_bits(img, want), (k, pipeline)
+            for key in ("pixel_samples", "rays", "shadow_probes", "glossy_probes"):
+                assert st[key] == wst[key], (k, pipeline, key)
+    # the frame changes between two traces without a resize: the lists follow the camera
+    gpu_ctx.set_option("tile_lists", -1)
+    gpu_ctx.resize(64, 48)
+    acc = np.zeros((48, 64, 3), np.float32)
+    for k in (0, 4, 7):
+        gpu_ctx.set_frame(cams[k], 555, 6, 1.0)
+        gpu_ctx.trace(k, 2, 1)
+    got, n = gpu_ctx.read_sum()
+    sc = oracle_mod.OracleScene(*scene)
+    sc.upload_env(gradient_env())
+    for k in (0, 4, 7):
+        part, _ = sc.render(cams[k], 555, 6, 1.0, 64, 48, k, 2)
+        for s in range(2):
+            one, _ = sc.render(cams[k], 555, 6, 1.0, 64, 48, k + s, 1)
+            acc = (acc + one).astype(np.float32)
+    assert n == 6 and _same_bits(got, acc)

@@ -31,5 +31,9 @@ c = np.array([st["bvh_extend_nodes"], st["bvh_extend_tris"], st["bvh_probe_nodes
 chunks = st["pixel_samples"] / 64.0
 print(name, "chunks %.0f" % chunks, "shadow probes", st["shadow_probes"], "glossy probes", st["glossy_probes"], "parked", st["parked_probes"],
       "left to the probe stages", st["deferred_probes"], "k_first ms", st["extend0_ms"], "probe stages ms", st["probe_ms"])
-for label, v in zip(("1-15 lanes", "16-31", "32-47", "48-64"), c):
-    print("  searches with %-10s %6.2f %% of the chunks" % (label, 100 * v / chunks))
+if len(sys.argv) > 3 and sys.argv[3] == "lists":        # library built with -DRT_PROBE_HISTO=3
+    for label, v in zip(("up to 4 triangles", "5-12", "13-31", "no list (hierarchy)"), c):
+        print("  camera-ray chunks with a list of %-20s %6.2f %%" % (label, 100 * v / chunks))
+else:
+    for label, v in zip(("1-15 lanes", "16-31", "32-47", "48-64"), c):
+        print("  searches with %-10s %6.2f %% of the chunks" % (label, 100 * v / chunks))

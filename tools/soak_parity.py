@@ -57,7 +57,7 @@ def case_for(seed, tmp, write_soup=None):
 
 
 def check_seed(ctx, seed, tmp, env, T, oracle=None, oracle_budget=4e9):
-    """Renders the case of one seed in the loop form and in four hierarchy forms (and with `oracle`, the CPU checker's
+    """Renders the case of one seed in the loop form and in five hierarchy forms (and with `oracle`, the CPU checker's
     module, every fourth seed by the checker too, while triangles x pixel-samples stays under `oracle_budget`).
     Returns (description, list of differences)."""
     scene, cam, w, h, spp, rec, clock, batches = case_for(seed, tmp, T._write_soup)
@@ -65,7 +65,7 @@ def check_seed(ctx, seed, tmp, env, T, oracle=None, oracle_budget=4e9):
     want, wst = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=3, batch=batches[0], cam=cam)
     line = "seed %d: %d tris %dx%d spp %d rec %d rays %d" % (seed, len(scene[0]), w, h, spp, rec, wst["rays"])
     diffs = []
-    for k, form in enumerate((1, 5, 7, 6)):
+    for k, form in enumerate((1, 5, 7, 6, 9)):
         # queues for the whole pass, or for a fraction of it (passes that do not fit take further rounds)
         rounds = (1, 3, 8, 2)[(seed + k) % 4]
         img, st = T._render(ctx, w, h, 0, spp, recursion=rec, clock=clock, pipeline=form, batch=batches[k % 3 + 1], cam=cam,
