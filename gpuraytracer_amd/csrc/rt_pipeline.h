@@ -6,8 +6,10 @@
 // loops.  Here a bounce is split into stages that each run as their own kernel over densely
 // packed queues:
 //
-//   first    depth 0 in one kernel: camera ray, closest hit, shading, the probe in place (all lanes of a wave
-//            want the same kind of probe there), rest of the bounce                   -> extend queue of depth 1
+//   first    depth 0 in one kernel: camera ray, closest hit (over the candidate list of the wave's pixel tile, else by
+//            the hierarchy), shading, the probe in place (all lanes of a wave want the same kind of probe there; chunks
+//            with few probes park them as records, idle lanes of later chunks take them up), rest of the bounce
+//                                                                                     -> extend queue of depth 1
 //   extend   closest hit (findIntersection) + everything of the bounce up to the probe loop;
 //            paths that need a probe go to the shadow or the glossy queue, paths that need none
 //            are finished (roulette) and go to the next extend queue
@@ -19,7 +21,8 @@
 //
 // The launch sequence of a pass is fixed (no decision needs a value read back from the device: a stage whose
 // queue region is empty ends at once), so rt_trace only enqueues work and can be captured in a HIP graph:
-//   rounds x ( first, [shadow, glossy of depth 0: the probes of chunks that had too few to run them in place],
+//   [candidate lists of the camera rays, when the frame has changed]
+//   rounds x ( first, [shadow, glossy of depth 0: the probe records the depth-0 kernel still had parked at its end],
 //              staged depths x ( extend, shadow, glossy ), tail ), resolve
 // The queues hold a fraction of a pass; a pass whose survivors do not fit goes on in the next round (MAX_ROUNDS), and
 // the kernels of a round that has nothing to do return on their first instruction.  The extend and probe stages take
@@ -603,7 +606,8 @@ __global__ __launch_bounds__(64) void k_build_tile_lists(DScene sc, DFrame fr, u
 // `ids` is wave-uniform.  Returns the triangle id (-1 = miss); isec as the fold leaves it.
 // The ids and the triangle records come through scalar loads (the index is wave-uniform).  Asking for the next round's
 // record before the current one is tested was tried and gained nothing: the other waves of the SIMD cover the wait.
-RT_DEV int closest_hit_list(const DScene &sc, const uint32_t *ids, uint32_t n, const Ray &ray, bool active, f4 &isec) {
+RT_DEV int closest_hit_list(const DScene &sc, const uint32_t *ids, uint32_t n, const Ray &ray, bool active, f4 &isec,
+                            BvhCounters &cnt) {
     typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
     const const_u32_ptr w = (const_u32_ptr)ids;
     isec.x = 0.0f; isec.y = 0.0f; isec.z = -1.0f; isec.w = 1.0f;
@@ -614,6 +618,12 @@ RT_DEV int closest_hit_list(const DScene &sc, const uint32_t *ids, uint32_t n, c
     for (uint32_t k = 1; k <= n; k++) {
         const int i = (int)((w[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu);
         const Tri t = load_tri(sc.geo, i);
+        // (measurement builds: a triangle test per lane with a ray, or the 64 lane slots of the wave's test)
+#if defined(RT_COUNT_WAVE_STEPS)
+        cnt.tris += bvh_count_step();
+#else
+        cnt.tris += run ? bvh_count_step() : 0u;
+#endif
         PlaneTest pt;
         const bool p = run & plane_test_closest(ray, t, isec, pt);
         if (__builtin_amdgcn_ballot_w64(p) != 0ull) {
@@ -990,7 +1000,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         // measurement build: chunks by the length of their tile's candidate list (up to 4, 5-12, 13-31, none: hierarchy)
         histo[listed == TILE_LIST_OVERFLOW ? 3u : (listed <= 4u ? 0u : (listed <= 12u ? 1u : 2u))]++;
 #endif
-        if (listed != TILE_LIST_OVERFLOW) hit = closest_hit_list(sc, list, listed, ray, live, isec);
+        if (listed != TILE_LIST_OVERFLOW) hit = closest_hit_list(sc, list, listed, ray, live, isec, bc);
         else hit = closest_hit_cfg<CFG>(sc, bv, ray, live, ws, isec, bc);
         SECTION_MARK(0);
         const float inv_det = 1.0f / isec.w;
