@@ -457,7 +457,10 @@ def main():
                         "traffic_source": provenance if comparable else "not measured for this configuration (%s)" % provenance,
                         "note": "no traversal step counts for this configuration (they need the measurement builds and a bundled "
                                 "scene): algorithmic bytes against HBM; the kernel waits for node and leaf records that miss "
-                                "LDS and L1 (memory_path, valu_issue)"}
+                                "LDS and L1 (memory_path, valu_issue)" if args.workload == "c3" else
+                                "traversal step counts were not collected in this run (--lane-utilisation 0, another target size "
+                                "or more than one rank): algorithmic bytes against HBM, which is not what bounds this kernel; the "
+                                "default single-GPU line reports bound valu with the useful-work fraction"}
             roof["bytes_per_launch"] = algo / ext_n
             roof["memory_path"] = memory_path
             if valu_issue is not None:
