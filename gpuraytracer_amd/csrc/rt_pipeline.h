@@ -196,6 +196,22 @@ struct KernelCfg {
     static constexpr int SHARE_BYTES = (BVH_ && RES_) ? 128 * WG_WAVES : 1;
 };
 
+// Wave priorities.  The SIMD's arbiter serves the wave with the higher priority first.  A wave that shades (camera ray, hit
+// attributes, materials, light sampling, queue records) starts chains of dependent global loads, and the sooner those
+// loads are issued the more of their latency the other waves' searches cover; a wave inside a search only reads LDS and
+// computes.  So the searches run at the lower priority.  Measured: cubes +2.5 %, _ObiWan +0.8 %, 1 M triangles +0.5 %;
+// priorities 3 / 0 and 1 / 0 give the same, the other way round (searches first) gains less.
+#ifndef RT_PRIO_SHADE
+#define RT_PRIO_SHADE 1
+#endif
+#ifndef RT_PRIO_SEARCH
+#define RT_PRIO_SEARCH 0
+#endif
+struct SearchPriority {
+    RT_DEV SearchPriority() { if (RT_PRIO_SHADE != RT_PRIO_SEARCH) __builtin_amdgcn_s_setprio(RT_PRIO_SEARCH); }
+    RT_DEV ~SearchPriority() { if (RT_PRIO_SHADE != RT_PRIO_SEARCH) __builtin_amdgcn_s_setprio(RT_PRIO_SHADE); }
+};
+
 // Fills the LDS of a traversal kernel and the scratch descriptors of the two hierarchies; every thread of the
 // workgroup calls it.  `with_light`: the kernel searches the hierarchy over the emissive triangles as well.
 template <class CFG>
@@ -208,6 +224,7 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
     ws.n_top = 0;
     lws = ws;
     share = (lds_u8_ptr)share_mem;
+    if (RT_PRIO_SHADE != RT_PRIO_SEARCH) __builtin_amdgcn_s_setprio(RT_PRIO_SHADE);
     if (!CFG::BVH) return;
     if (CFG::RES) {
         // node records are 80 bytes = 5 float4, leaf records 4 float4
@@ -259,12 +276,14 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
 template <class CFG>
 RT_DEV int closest_hit_cfg(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, const typename CFG::WS &ws, f4 &isec,
                            BvhCounters &cnt) {
+    SearchPriority prio;
     if (CFG::BVH) return closest_hit_bvh(sc, bv, ray, active, 0, sc.count, -1, 1.0f, ws, isec, cnt);
     return closest_hit_bf(sc, ray, isec);
 }
 template <class CFG>
 RT_DEV bool shadow_any_hit_cfg(const DScene &sc, const DBvh &bv, const Ray &probe, float max_t, int current, bool run,
                                const typename CFG::WS &ws, lds_u8_ptr share, BvhCounters &cnt) {
+    SearchPriority prio;
     if (CFG::SHARE) return shadow_any_hit_shared<CFG::NODE_BUDGET>(sc, bv, probe, max_t, current, run, ws, share, cnt);
     if (CFG::BVH) return shadow_any_hit_bvh(sc, bv, probe, max_t, current, run, ws, cnt);
     return shadow_any_hit_bf(sc, probe, max_t, current, run);
@@ -273,6 +292,7 @@ template <class CFG>
 RT_DEV int glossy_search_cfg(const DScene &sc, const DBvh &bv, const DBvh &lbv, const Ray &probe, int current, bool run,
                              int &light_id, f4 &lsec, const typename CFG::WS &ws, const typename CFG::WS &lws, lds_u8_ptr share,
                              BvhCounters &cnt) {
+    SearchPriority prio;
 #ifdef RT_DEBUG_PROBE
     if (CFG::BVH) {
         int a_id = -1, b_id = -1; f4 a_sec, b_sec;
