@@ -76,6 +76,7 @@ constexpr float INV_UINT_MAX_F = 1.0f / 4294967296.0f;
 struct DScene {
     const float4 *geo;
     const float4 *shade;
+    const float4 *shade03;       // planes 0-3 of `shade` (what every hit reads): the same memory, or a workgroup's LDS copy of it
     const float4 *mats;          // 3 x float4 per material
     const int *has_tex;
     const uint32_t *const *atlas; // one pointer per layer, null = layer never uploaded (all zero)
@@ -201,10 +202,10 @@ struct ShadeRec {
 RT_DEV ShadeRec load_shade(const DScene &sc, int i) {
     ShadeRec r;
     if (i >= 0 && i < sc.count) {
-        const float4 a = sc.shade[(size_t)0 * sc.count + i];
-        const float4 b = sc.shade[(size_t)1 * sc.count + i];
-        const float4 c = sc.shade[(size_t)2 * sc.count + i];
-        const float4 d = sc.shade[(size_t)3 * sc.count + i];
+        const float4 a = sc.shade03[(size_t)0 * sc.count + i];
+        const float4 b = sc.shade03[(size_t)1 * sc.count + i];
+        const float4 c = sc.shade03[(size_t)2 * sc.count + i];
+        const float4 d = sc.shade03[(size_t)3 * sc.count + i];
         r.mat = __float_as_uint(a.w);
         r.n0 = mk3(a.x, a.y, a.z); r.n1 = mk3(b.x, b.y, b.z); r.n2 = mk3(c.x, c.y, c.z);
         r.tex_p[0] = b.w; r.tex_p[1] = c.w;

@@ -65,11 +65,15 @@ namespace rt {
 #ifndef RT_WAVES_PER_CU
 #define RT_WAVES_PER_CU 16
 #endif
+// Waves per workgroup.  The waves of a workgroup share its LDS copy of the hierarchies, so one workgroup of 16 waves per CU
+// holds that copy once where two of 8 held it twice; the 46 KB that frees take the shading planes and materials of a
+// resident scene (stage_shading) or a larger node cache (stage_hierarchies).  Measured against 8: cubes +1.2 %,
+// _ObiWan +1 %, 1 M triangles +0.5 %.
 #ifndef RT_WG_WAVES
-#define RT_WG_WAVES 8
+#define RT_WG_WAVES 16
 #endif
 constexpr int PIPE_WAVES = 256 * RT_WAVES_PER_CU;    // persistent grid, all waves resident
-constexpr int WG_WAVES = RT_WG_WAVES;                // waves per workgroup: they share the LDS copy of the hierarchy's top
+constexpr int WG_WAVES = RT_WG_WAVES;
 static_assert(PIPE_WAVES % WG_WAVES == 0, "the grid is a whole number of workgroups");
 
 // Wave-uniform by construction; readfirstlane tells the compiler so, which moves everything derived from it
@@ -168,6 +172,9 @@ RT_DEV uint32_t tile_number(uint32_t tx, uint32_t ty, uint32_t tiles_x, uint32_t
 //   BVH    hierarchy traversal (false: the reference's loops over all triangles)
 //   SHARE  any-hit searches shared among the lanes of a wave: 0 off, 1 on, 2 on with a node-step budget per round
 //   RES    the whole hierarchy, leaf triangles included, is staged into LDS (scenes of a few hundred triangles)
+#ifndef RT_LDS_SHADE_KB
+#define RT_LDS_SHADE_KB (RT_WG_WAVES >= 16 ? 44 : 0)    // LDS for the shading planes and materials of a resident scene
+#endif
 #ifndef RT_RES_STACK
 #define RT_RES_STACK 16
 #endif
@@ -179,6 +186,9 @@ constexpr int RES_STACK = RT_RES_STACK;              // traversal stack entries 
 #define RT_RES_KB 46
 #endif
 constexpr int RES_BYTES = RT_RES_KB * 1024;                 // room for the resident records: 80 bytes per node, 64 per leaf slot, both hierarchies
+// LDS a non-resident kernel has beyond stacks of BVH_STACK entries (hierarchies of lesser depth leave their stacks' rest to
+// the node cache as well): 16 KB with two workgroups per CU, 26 KB with one (154 KB in all)
+constexpr int NODE_CACHE_MIN_INTS = WG_WAVES >= 16 ? 6656 : (BVH_TOP_NODES + BVH_LIGHT_TOP_NODES) * 16;
 template <bool BVH_, int SHARE_, bool RES_>
 struct KernelCfg {
     static constexpr bool BVH = BVH_;
@@ -187,13 +197,13 @@ struct KernelCfg {
     static constexpr int STACK = RES_ ? RES_STACK : BVH_STACK;
     static constexpr int NODE_BUDGET = SHARE_ == 2 ? SHARE_NODE_BUDGET : 0;
     typedef BvhScratchT<RES_> WS;
-    // LDS of a workgroup: the stacks; then either the cached tops of the two hierarchies (192 + 64 nodes; with SHARE the
-    // last 16 node slots of the second are the waves' 128-byte exchange areas) or the resident scene and 1 KB of
-    // exchange areas.  80 KB at most: two workgroups per CU.
-    // (the non-resident form carves stacks, cached nodes and exchange areas out of one array at run time, see stage_hierarchies)
-    static constexpr int STACK_INTS = !BVH_ ? 64 : (RES_ ? STACK * 64 * WG_WAVES : BVH_STACK * 64 * WG_WAVES + (BVH_TOP_NODES + BVH_LIGHT_TOP_NODES) * 16);
+    // LDS of a workgroup: the stacks; then either cached nodes of the two hierarchies and the waves' 128-byte exchange
+    // areas (carved out of one array at run time, see stage_hierarchies), or the resident scene, the exchange areas and
+    // the shading planes (stage_shading).  At most 156 KB of a CU's 160 KB: one workgroup of 16 waves per CU.
+    static constexpr int STACK_INTS = !BVH_ ? 64 : (RES_ ? STACK * 64 * WG_WAVES : BVH_STACK * 64 * WG_WAVES + NODE_CACHE_MIN_INTS);
     static constexpr int SCENE_V4F = (BVH_ && RES_) ? RES_BYTES / 16 : 1;
     static constexpr int SHARE_BYTES = (BVH_ && RES_) ? 128 * WG_WAVES : 1;
+    static constexpr int SHADE_V4F = (BVH_ && RES_ && RT_LDS_SHADE_KB > 0) ? RT_LDS_SHADE_KB * 64 : 1;
 };
 
 // Wave priorities.  The SIMD's arbiter serves the wave with the higher priority first.  A wave that shades (camera ray, hit
@@ -246,11 +256,11 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
         // The stacks take what the depth of the hierarchies asks for (bv.stack_entries per lane) and the rest of the
         // array caches 32-byte nodes: the first ones of the light hierarchy (all of it if it has up to 256 nodes and a
         // third of the room suffices) and, in what is left, the first ones of the scene's.  The waves' exchange areas are
-        // the last 1024 bytes.
+        // the last 128 bytes per wave.
         const int entries = bv.stack_entries;
         ws.stack = stack_mem + wv * (entries * 64) + lane;
         v4f *free_mem = (v4f *)(stack_mem + WG_WAVES * entries * 64);
-        const int room = (CFG::STACK_INTS - WG_WAVES * entries * 64) / 8 - 32;         // 32-byte node slots
+        const int room = (CFG::STACK_INTS - WG_WAVES * entries * 64) / 8 - 4 * WG_WAVES;         // 32-byte node slots (less the exchange areas)
         int light_slots = 0;
         if (with_light && lbv.enabled) {
             light_slots = lbv.n_nodes < 256 ? lbv.n_nodes : 256;
@@ -270,7 +280,22 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
 #define RT_TRAVERSAL_LDS(CFG)                                              \
     __shared__ int stack_mem[CFG::STACK_INTS];                             \
     __shared__ v4f scene_mem[CFG::SCENE_V4F];                              \
-    __shared__ unsigned char share_mem[CFG::SHARE_BYTES]
+    __shared__ unsigned char share_mem[CFG::SHARE_BYTES];                  \
+    __shared__ v4f shade_mem[CFG::SHADE_V4F]
+
+// Resident scenes: the four shading planes every hit reads and the material table go to LDS as well when they fit
+// what the stacks and the hierarchies leave of a CU's LDS (every thread of the workgroup calls this).
+template <class CFG>
+RT_DEV void stage_shading(DScene &sc, v4f *shade_mem) {
+    if (!CFG::RES || CFG::SHADE_V4F <= 1) return;
+    const int n_planes = 4 * sc.count, n_mats = 3 * sc.n_mat;
+    if (n_planes + n_mats > CFG::SHADE_V4F) return;
+    for (int i = threadIdx.x; i < n_planes; i += blockDim.x) shade_mem[i] = ((const v4f *)sc.shade)[i];
+    for (int i = threadIdx.x; i < n_mats; i += blockDim.x) shade_mem[n_planes + i] = ((const v4f *)sc.mats)[i];
+    __syncthreads();
+    sc.shade03 = (const float4 *)shade_mem;
+    sc.mats = (const float4 *)(shade_mem + n_planes);
+}
 
 // The three searches of a bounce in the form the kernel's configuration selects.
 template <class CFG>
@@ -625,7 +650,8 @@ __global__ __launch_bounds__(64) void k_build_tile_lists(DScene sc, DFrame fr, u
 // findIntersection (raytracer.glsl:217-235) over the `n` triangles of a tile's list (ids[1..n], 16 bits each, ascending).
 // `ids` is wave-uniform.  Returns the triangle id (-1 = miss); isec as the fold leaves it.
 // The ids and the triangle records come through scalar loads (the index is wave-uniform).  Asking for the next round's
-// record before the current one is tested was tried and gained nothing: the other waves of the SIMD cover the wait.
+// record before the current one is tested was tried and gained nothing: the other waves of the SIMD cover the wait.  So was
+// keeping the list's words in a vector register (an id by v_readlane instead of a scalar load): cubes +0.5 %, _ObiWan -1.5 %.
 RT_DEV int closest_hit_list(const DScene &sc, const uint32_t *ids, uint32_t n, const Ray &ray, bool active, f4 &isec,
                             BvhCounters &cnt) {
     typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
@@ -804,6 +830,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     typename CFG::WS ws, lws;
     lds_u8_ptr share;
     stage_hierarchies<CFG>(bv, bv, false, stack_mem, scene_mem, share_mem, ws, lws, share);
+    stage_shading<CFG>(sc, shade_mem);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     uint32_t n_rays = 0;
@@ -895,6 +922,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
     typename CFG::WS ws, lws;
     lds_u8_ptr share;
     stage_hierarchies<CFG>(bv, lbv, true, stack_mem, scene_mem, share_mem, ws, lws, share);
+    stage_shading<CFG>(sc, shade_mem);
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
     uint32_t n_paths = 0, n_shadow = 0, n_glossy = 0, fill_next = 0;
@@ -1219,6 +1247,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, RT_MIN_WAVES) void k_tail(DScene sc,
     typename CFG::WS ws, lws;
     lds_u8_ptr share;
     stage_hierarchies<CFG>(bv, lbv, true, stack_mem, scene_mem, share_mem, ws, lws, share);
+    stage_shading<CFG>(sc, shade_mem);
     BvhCounters bc, pc;
     bc.nodes = 0; bc.tris = 0; pc.nodes = 0; pc.tris = 0;
     uint32_t n_rays = 0, n_shadow = 0, n_glossy = 0;
@@ -1399,6 +1428,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     typename CFG::WS ws, lws;
     lds_u8_ptr share;
     stage_hierarchies<CFG>(bv, bv, false, stack_mem, scene_mem, share_mem, ws, lws, share);
+    stage_shading<CFG>(sc, shade_mem);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     uint32_t fill_next = b.n_ext[q_in ^ 1][wave], n_done = 0;
@@ -1444,6 +1474,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
     typename CFG::WS ws, lws;
     lds_u8_ptr share;
     stage_hierarchies<CFG>(bv, lbv, true, stack_mem, scene_mem, share_mem, ws, lws, share);
+    stage_shading<CFG>(sc, shade_mem);
     BvhCounters bc;
     bc.nodes = 0; bc.tris = 0;
     uint32_t fill_next = b.n_ext[q_in ^ 1][wave], n_done = 0;
