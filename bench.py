@@ -143,14 +143,14 @@ def load_workload(g, args):
             % (len(scene[0]), args.atlas), layers)
 
 
-PROFILE_ROUND = "r03"
+PROFILE_PREFIX = "r03"
 
 
 def profile_counters(workload, kernel_key):
     """Per-launch counters of one kernel from rocprofv3 passes over this command (separate --pmc runs, made by
     tools/prof_bench.sh and tools/prof_summary.py and kept under profiles/): FETCH_SIZE_KB (to be doubled: gfx950
     reports half of wide reads), WRITE_SIZE_KB, vector instructions.  Returns (counters, provenance) or (None, why)."""
-    name = "%s_pmc_counters_%s.json" % (PROFILE_ROUND, workload)
+    name = "%s_pmc_counters_%s.json" % (PROFILE_PREFIX, workload)
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             table = json.load(f)

@@ -1,8 +1,8 @@
 """A slice of the soak run (tools/soak_parity.py) inside the GPU tests: random triangle soups, bundled scenes with
 random cameras, cameras with exact zeros in the matrix and soups of 30 000 to 160 000 triangles; the library's default
 forms and three other hierarchy forms against the loops over all triangles (the reference's own algorithm), bit for bit
-with equal counters, every fourth scene also against the CPU checker.  The seeds change from round to round of the
-build (SEED_BASE) so that the slice does not keep testing the scenes the code was last debugged on."""
+with equal counters, every fourth scene also against the CPU checker.  SEED_BASE is moved whenever the kernels change
+in a larger way, so that the slice does not keep testing the scenes the code was last debugged on."""
 import os
 import sys
 
