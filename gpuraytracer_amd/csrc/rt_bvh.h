@@ -82,6 +82,10 @@ struct BvhScratchT {
     lds_v4f_ptr top;      // LDS address space: the reads become ds_read_b128, not generic-address loads
     int n_top;
     lds_v4f_ptr leaves;   // RES: the leaf records (4 x float4 per slot)
+    // memory form: the grid of the 15-bit planes in LDS, (qbase - qscale) x, y, z, then qscale x, y, z (bvh_stage_grid).
+    // Uniform values that every search needs but that are not worth a scalar register each for the whole kernel: the
+    // kernels' scalar registers do not hold all their arguments, and what overflows is parked in vector lanes.
+    lds_f32_ptr grid;
 };
 typedef BvhScratchT<false> BvhScratch;
 
@@ -91,6 +95,13 @@ RT_DEV int bvh_stage_top(const DBvh &bv, v4f *top, int max_nodes = BVH_TOP_NODES
     for (int i = threadIdx.x; i < n_top * 2; i += blockDim.x) top[i] = ((const v4f *)bv.qnodes)[i];
     __syncthreads();
     return n_top;
+}
+RT_DEV void bvh_stage_grid(const DBvh &bv, float *grid) {
+    if (threadIdx.x < 3) {
+        grid[threadIdx.x] = bv.qbase[threadIdx.x] - bv.qscale[threadIdx.x];
+        grid[3 + threadIdx.x] = bv.qscale[threadIdx.x];
+    }
+    __syncthreads();
 }
 // Node layout of a resident hierarchy (80 bytes, 20 words), made for slab tests without min/max.  Which plane of a
 // box a ray meets first along an axis follows from the sign of its direction alone, so a lane can fetch "near" and
@@ -161,8 +172,8 @@ RT_DEV bool bvh_ray_ok(const Ray &ray, float max_abs_coord) {
     return ((s - s) == 0.0f) & (m < BVH_MAX_COORD);      // s - s is NaN when any component is NaN or infinite
 }
 
-template <bool RES>
-RT_DEV BvhRay bvh_ray_setup(const Ray &ray, const DBvh &bv) {
+template <bool RES, class WS>
+RT_DEV BvhRay bvh_ray_setup(const Ray &ray, const DBvh &bv, const WS &ws) {
     const float max_abs_coord = bv.max_abs_coord;
     BvhRay b;
     const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.o.x), __builtin_fabsf(ray.o.y)),
@@ -196,13 +207,13 @@ RT_DEV BvhRay bvh_ray_setup(const Ray &ray, const DBvh &bv) {
         // a plane is qbase + (F - 1) * qscale: F * (qscale * inv) - (origin +- r - (qbase - qscale)) * inv.  The rounding of
         // these few operations on coordinates stays as far below the widening r as that of the plain form.
         const float rx = __builtin_copysignf(r, b.inv.x), ry = __builtin_copysignf(r, b.inv.y), rz = __builtin_copysignf(r, b.inv.z);
-        const f3 o = mk3(ray.o.x - (bv.qbase[0] - bv.qscale[0]), ray.o.y - (bv.qbase[1] - bv.qscale[1]), ray.o.z - (bv.qbase[2] - bv.qscale[2]));
+        const f3 o = mk3(ray.o.x - ws.grid[0], ray.o.y - ws.grid[1], ray.o.z - ws.grid[2]);
         b.ca = mk3((o.x + rx) * b.inv.x, (o.y + ry) * b.inv.y, (o.z + rz) * b.inv.z);
         b.cb = mk3((o.x - rx) * b.inv.x, (o.y - ry) * b.inv.y, (o.z - rz) * b.inv.z);
         if (flat_x) { b.ca.x = FAR; b.cb.x = -FAR; }
         if (flat_y) { b.ca.y = FAR; b.cb.y = -FAR; }
         if (flat_z) { b.ca.z = FAR; b.cb.z = -FAR; }
-        b.inv = mk3(b.inv.x * bv.qscale[0], b.inv.y * bv.qscale[1], b.inv.z * bv.qscale[2]);
+        b.inv = mk3(b.inv.x * ws.grid[3], b.inv.y * ws.grid[4], b.inv.z * ws.grid[5]);
         b.off_x = (int)((__float_as_uint(b.inv.x) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
         b.off_y = (int)((__float_as_uint(b.inv.y) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
         b.off_z = (int)((__float_as_uint(b.inv.z) >> 31) ? PERM_NEAR_HI : PERM_NEAR_LO);
@@ -462,7 +473,7 @@ RT_DEV void closest_fold_redo(const DScene &sc, const Ray &ray, bool redo, int b
 template <class WS>
 RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, int begin_id, int end_id,
                            int current, float w_init, const WS &ws, f4 &isec, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv, ws);
     ClosestFold cf;
     closest_fold_reset(cf, w_init);
     auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, current, cf); return true; };
@@ -498,7 +509,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
     lds_u8_ptr flags = scratch, table = scratch + 64;
     flags[lane] = 0;
     int owner = lane;
-    BvhRay br = bvh_ray_setup<WS::RES>(ray, bv);
+    BvhRay br = bvh_ray_setup<WS::RES>(ray, bv, ws);
     TravState ts;
     trav_begin(ws, ts, active);
     auto leaf = [&](int slot) -> bool {
@@ -552,7 +563,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
 template <class WS>
 RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, float max_t, int current, bool active,
                                const WS &ws, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv, ws);
     const bool ok = br.finite && ((max_t - max_t) == 0.0f);
     bool blocked = false;
     auto leaf = [&](int slot) -> bool {
@@ -576,7 +587,7 @@ RT_DEV bool shadow_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray,
 template <class WS>
 RT_DEV bool closer_any_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, const f4 &isec, int current, bool active,
                                const WS &ws, BvhCounters &cnt) {
-    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv);
+    const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv, ws);
     const bool bounded = isec.z >= 0.0f;                 // a light was hit: only triangles not farther than it matter
     const float t_light = isec.z / isec.w;
     const bool ok = br.finite && (!bounded || (t_light - t_light) == 0.0f);
@@ -685,7 +696,10 @@ __global__ __launch_bounds__(64) void k_closest_hit_batch_bvh(DScene sc, DBvh bv
                                                               DStats *__restrict__ stats) {
     __shared__ int stack_mem[BVH_STACK * 64];
     __shared__ v4f top_mem[128 * 2];              // single-wave workgroups: a small top only
+    __shared__ float grid_mem[8];
     BvhScratch ws;
+    bvh_stage_grid(bv, grid_mem);
+    ws.grid = (lds_f32_ptr)grid_mem;
     ws.stack = stack_mem + threadIdx.x;
     ws.top = (lds_v4f_ptr)top_mem;
     ws.leaves = nullptr;

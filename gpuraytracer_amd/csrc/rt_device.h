@@ -350,7 +350,7 @@ RT_DEV f3 camera_origin(const DFrame &fr) {
     return mk3(o4[0], o4[1], o4[2]);
 }
 
-RT_DEV Ray camera_ray(const DFrame &fr, uint32_t tx, uint32_t ty, uint32_t &seed) {
+RT_DEV Ray camera_ray(const DFrame &fr, uint32_t tx, uint32_t ty, uint32_t &seed, const float *matrix = nullptr) {
     const float W = (float)fr.width, H = (float)fr.height;
     const float inv_width = 1.0f / W, inv_height = 1.0f / H;
     const float j1 = unit_float(seed) * inv_width;
@@ -358,7 +358,7 @@ RT_DEV Ray camera_ray(const DFrame &fr, uint32_t tx, uint32_t ty, uint32_t &seed
     const f3 d0 = mk3(((float)(int)tx - 0.5f * W + 0.5f) * inv_height, ((float)(int)ty + 0.5f) * inv_height - 0.5f, 0.5f);
     const f3 dtctor = normalize(d0 + mk3(j1, j2, 0.0f));
     const f3 dir3 = normalize(dtctor - mk3(0.0f, 0.0f, 0.0f));
-    const float *M = fr.cam;
+    const float *M = matrix ? matrix : fr.cam;
     float o4[4], d4[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
