@@ -59,7 +59,7 @@ L2_PEAK_GBPS = 34500.0          # all 8 XCDs (MI355X_MICROARCH.md)
 # vector instructions of a traversal step (assembly listing of the traversal loops): a node step of the hierarchy resident in
 # LDS, of the hierarchy read from memory (12 byte-selects more: its planes are 15-bit grid positions), a triangle test
 # (17 to the plane test, 24 more to the inside test)
-INSTS_NODE_RESIDENT, INSTS_NODE_MEMORY, INSTS_TRIANGLE = 36, 48, 41
+INSTS_NODE_RESIDENT, INSTS_NODE_MEMORY, INSTS_TRIANGLE = 32, 46, 41
 FLOPS_PER_CLOSEST_TEST = 35     # raytracer.glsl:135-158, full pass
 FLOPS_PER_PROBE_TEST = 34       # raytracer.glsl:171-195
 

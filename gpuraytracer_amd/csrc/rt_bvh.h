@@ -82,6 +82,7 @@ struct BvhScratchT {
     lds_v4f_ptr top;      // LDS address space: the reads become ds_read_b128, not generic-address loads
     int n_top;
     lds_v4f_ptr leaves;   // RES: the leaf records (4 x float4 per slot)
+    int root;             // what a traversal starts with: node 0, or (RES) the LDS address of its record
     // memory form: the grid of the 15-bit planes in LDS, (qbase - qscale) x, y, z, then qscale x, y, z (bvh_stage_grid).
     // Uniform values that every search needs but that are not worth a scalar register each for the whole kernel: the
     // kernels' scalar registers do not hold all their arguments, and what overflows is parked in vector lanes.
@@ -108,7 +109,8 @@ RT_DEV void bvh_stage_grid(const DBvh &bv, float *grid) {
 // "far" straight away if it may pick the address: per axis and child the words (lo, hi, lo) are stored, and a lane
 // reads two consecutive words from offset 0 (direction >= 0: lo then hi) or from offset 1 (hi then lo).
 //   words 0..5   x: lo0 hi0 lo0 lo1 hi1 lo1      words 6..11  y, 12..17 z likewise
-//   words 18,19  child links: inner node = byte offset of its record, leaf = the (negative) leaf code as it is
+//   words 18,19  child links: inner node = LDS address of its record (so that a step needs no base), leaf = the
+//                 (negative) leaf code as it is
 // That takes the 12 min/max of a node step away (they issue at half the rate of multiply-adds on this chip).
 #ifndef RT_RES_NODE_WORDS
 #define RT_RES_NODE_WORDS 20
@@ -132,7 +134,7 @@ RT_DEV void bvh_stage_nodes_resident(const DBvh &bv, float *dst) {
             v = s[6 * child + 3 * which + axis];
         } else {
             const int link = __float_as_int(s[12 + (k - 18)]);
-            v = __int_as_float(link >= 0 ? link * RES_NODE_BYTES : link);
+            v = __int_as_float(link >= 0 ? link * RES_NODE_BYTES + (int)(uintptr_t)(lds_f32_ptr)dst : link);
         }
         dst[i] = v;
     }
@@ -270,7 +272,7 @@ constexpr int STACK_BOTTOM = -1;          // ~STACK_BOTTOM = leaf code 0: first 
 template <class WS>
 RT_DEV void trav_begin(const WS &ws, TravState &ts, bool run) {
     ws.stack[0] = STACK_BOTTOM;
-    ts.node = 0; ts.sp = 1; ts.run = run;
+    ts.node = ws.root; ts.sp = 1; ts.run = run;
 }
 
 // Advances every running lane of the wave.  `leaf(slot)` is called for every triangle slot of every leaf whose
@@ -293,6 +295,10 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
         if (running == 0ull || (!at_least_one && 64 - (int)__popcll(running) >= stop_at)) break;
         // a divergent loop: lanes leave as they reach a leaf or finish, and the wave goes on when none is left
         int budget = node_budget;
+        // the first free entry of the lane's stack as an LDS address (entries of a lane are 64 apart): a step then needs no
+        // multiplication for its accesses
+        typedef __attribute__((address_space(3))) int *lds_stack_ptr;
+        lds_stack_ptr top = (lds_stack_ptr)stack + 64 * sp;
         while (run && node >= 0 && (!BUDGETED || budget-- > 0)) {      // `run` does not change in this loop
             float in0, out0, in1, out1;
             int c0, c1;
@@ -300,7 +306,7 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
             const float lim = t_limit();
             if (WS::RES) {
                 // `node` is the byte offset of the record; (near, far) per axis and child through the lane's own offsets
-                const lds_byte_ptr rec = (lds_byte_ptr)ws.top + node;
+                const lds_byte_ptr rec = (lds_byte_ptr)(uintptr_t)node;
                 const lds_f32_ptr px = (lds_f32_ptr)(rec + br.off_x), py = (lds_f32_ptr)(rec + br.off_y), pz = (lds_f32_ptr)(rec + br.off_z);
                 const lds_i32_ptr links = (lds_i32_ptr)(rec + 72);
                 const float n0x = px[0], f0x = px[1], n1x = px[3], f1x = px[4];
@@ -347,15 +353,16 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
             const int near = __builtin_amdgcn_inverse_ballot_w64(m0 & (first0 | ~m1)) ? c0 : c1;
             // the farther child goes on the stack if both are entered; stored in any case (slot sp is free), which
             // spares the step a branch
-            stack[64 * sp] = __builtin_amdgcn_inverse_ballot_w64(first0) ? c1 : c0;
-            sp += both ? 1 : 0;
+            *top = __builtin_amdgcn_inverse_ballot_w64(first0) ? c1 : c0;
+            top += both ? 64 : 0;
             // neither child entered: on to the top of the stack (at the bottom: the empty leaf)
             const bool pop = __builtin_amdgcn_inverse_ballot_w64(~any_m);
-            sp -= pop ? 1 : 0;
+            top -= pop ? 64 : 0;
             int next = near;
-            if (pop) next = stack[64 * sp];
+            if (pop) next = *top;
             node = next;
         }
+        sp = (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)(lds_stack_ptr)stack) >> 8);
         if (run && (!BUDGETED || node < 0)) {      // a leaf
             const int code = ~node;
             const int first = code >> 3, n = code & 7;
@@ -703,6 +710,7 @@ __global__ __launch_bounds__(64) void k_closest_hit_batch_bvh(DScene sc, DBvh bv
     ws.stack = stack_mem + threadIdx.x;
     ws.top = (lds_v4f_ptr)top_mem;
     ws.leaves = nullptr;
+    ws.root = 0;
     ws.n_top = bvh_stage_top(bv, top_mem, 128);
     BvhCounters cnt;
     cnt.nodes = 0; cnt.tris = 0;

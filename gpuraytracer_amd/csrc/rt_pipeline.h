@@ -233,6 +233,7 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
     ws.leaves = nullptr;
     ws.n_top = 0;
     ws.grid = nullptr;
+    ws.root = 0;
     lws = ws;
     share = (lds_u8_ptr)share_mem;
     if (RT_PRIO_SHADE != RT_PRIO_SEARCH) __builtin_amdgcn_s_setprio(RT_PRIO_SHADE);
@@ -243,9 +244,11 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
         v4f *lnodes = leaves + 4 * bv.n_slots, *lleaves = lnodes + res_nodes_v4f(lbv.n_nodes);
         bvh_stage_nodes_resident(bv, (float *)nodes);
         ws.n_top = bv.n_nodes;
+        ws.root = (int)(uintptr_t)(lds_v4f_ptr)nodes;
         ws.leaves = (lds_v4f_ptr)leaves;
         bvh_stage_leaves(bv, leaves);
         lws.top = (lds_v4f_ptr)lnodes;
+        lws.root = (int)(uintptr_t)(lds_v4f_ptr)lnodes;
         lws.leaves = (lds_v4f_ptr)lleaves;
         if (with_light) {
             bvh_stage_nodes_resident(lbv, (float *)lnodes);
@@ -1590,7 +1593,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
             br = bvh_ray_setup<CFG::RES>(ray, bv, ws);
             closest_fold_reset(cf, 1.0f);
             busy = true;
-            ts.node = 0; ts.sp = 1; ts.run = br.finite;
+            ts.node = ws.root; ts.sp = 1; ts.run = br.finite;
         }
         if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
         auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, -1, cf); return true; };
