@@ -174,7 +174,7 @@ bool use_accel(const rt_context *ctx) {
 bool fits_lds(const rt_context *ctx) {
     const rt_context::DevBvh &a = ctx->bvh, &l = ctx->light_bvh;
     const int bytes = RES_NODE_BYTES * (a.n_nodes + (l.ok ? l.n_nodes : 0)) + 32 + 64 * (a.n_slots + (l.ok ? l.n_slots : 0));
-    return bytes <= RES_BYTES && a.depth < RES_STACK && (!l.ok || l.depth < RES_STACK);
+    return bytes <= RES_BYTES && a.depth < RES_STACK && (!l.ok || l.depth < RES_STACK) && shading_fits_lds((int)ctx->count, (int)ctx->n_mat);
 }
 
 void free_bvh(rt_context::DevBvh &b) {

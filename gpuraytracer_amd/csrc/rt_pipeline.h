@@ -222,6 +222,15 @@ struct SearchPriority {
     RT_DEV ~SearchPriority() { if (RT_PRIO_SHADE != RT_PRIO_SEARCH) __builtin_amdgcn_s_setprio(RT_PRIO_SHADE); }
 };
 
+// An LDS address as a plain number in a scalar register.  Left as "start of the array + offset" the compiler keeps the
+// array's start (beyond the 16 bits of an LDS instruction's offset field) apart from the rest and adds it again for every
+// access: three vector additions per triangle test.
+RT_DEV lds_v4f_ptr opaque_lds(const v4f *p) {
+    uint32_t a = (uint32_t)(uintptr_t)(lds_v4f_ptr)p;
+    asm volatile("" : "+s"(a));
+    return (lds_v4f_ptr)(uintptr_t)a;
+}
+
 // Fills the LDS of a traversal kernel and the scratch descriptors of the two hierarchies; every thread of the
 // workgroup calls it.  `with_light`: the kernel searches the hierarchy over the emissive triangles as well.
 template <class CFG>
@@ -245,11 +254,11 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
         bvh_stage_nodes_resident(bv, (float *)nodes);
         ws.n_top = bv.n_nodes;
         ws.root = (int)(uintptr_t)(lds_v4f_ptr)nodes;
-        ws.leaves = (lds_v4f_ptr)leaves;
+        ws.leaves = opaque_lds(leaves);
         bvh_stage_leaves(bv, leaves);
         lws.top = (lds_v4f_ptr)lnodes;
         lws.root = (int)(uintptr_t)(lds_v4f_ptr)lnodes;
-        lws.leaves = (lds_v4f_ptr)lleaves;
+        lws.leaves = opaque_lds(lleaves);
         if (with_light) {
             bvh_stage_nodes_resident(lbv, (float *)lnodes);
             lws.n_top = lbv.n_nodes;
@@ -292,13 +301,15 @@ RT_DEV void stage_hierarchies(const DBvh &bv, const DBvh &lbv, bool with_light, 
     __shared__ unsigned char share_mem[CFG::SHARE_BYTES];                  \
     __shared__ v4f shade_mem[CFG::SHADE_V4F]
 
-// Resident scenes: the four shading planes every hit reads and the material table go to LDS as well when they fit
-// what the stacks and the hierarchies leave of a CU's LDS (every thread of the workgroup calls this).
+// Resident scenes: the four shading planes every hit reads and the material table go to LDS as well (every thread of the
+// workgroup calls this).  That they fit is part of what makes a scene resident (shading_fits_lds, checked by the host),
+// so that the kernels know at compile time where these reads go: LDS instructions, not generic-address loads.
+constexpr int LDS_SHADE_V4F = RT_LDS_SHADE_KB * 64;
+inline bool shading_fits_lds(int count, int n_mat) { return LDS_SHADE_V4F <= 1 || 4 * (long long)count + 3 * (long long)n_mat <= LDS_SHADE_V4F; }
 template <class CFG>
 RT_DEV void stage_shading(DScene &sc, v4f *shade_mem) {
     if (!CFG::RES || CFG::SHADE_V4F <= 1) return;
     const int n_planes = 4 * sc.count, n_mats = 3 * sc.n_mat;
-    if (n_planes + n_mats > CFG::SHADE_V4F) return;
     for (int i = threadIdx.x; i < n_planes; i += blockDim.x) shade_mem[i] = ((const v4f *)sc.shade)[i];
     for (int i = threadIdx.x; i < n_mats; i += blockDim.x) shade_mem[n_planes + i] = ((const v4f *)sc.mats)[i];
     __syncthreads();
