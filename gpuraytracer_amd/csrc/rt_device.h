@@ -137,6 +137,21 @@ RT_DEV Tri load_tri(const float4 *geo, int i) {
     t.v = mk3(c.y, c.z, c.w);
     return t;
 }
+// The same for an index the whole wave shares and that the compiler knows to be small (a 16-bit id from a candidate
+// list): i * 48 of such a number becomes a 24-bit multiplication, which only the vector unit has, and the product has to
+// be carried back to the scalar unit for the load.  The empty asm hides how small the index is: a scalar multiplication.
+RT_DEV Tri load_tri_uniform(const float4 *geo, uint32_t i) {
+    asm volatile("" : "+s"(i));
+    const uint32_t off = i * 48u;
+    const const_v4f_ptr g = (const_v4f_ptr)((const __attribute__((address_space(4))) char *)geo + off);
+    const v4f a = g[0], b = g[1], c = g[2];
+    Tri t;
+    t.n = mk3(a.x, a.y, a.z);
+    t.p = mk3(a.w, b.x, b.y);
+    t.u = mk3(b.z, b.w, c.x);
+    t.v = mk3(c.y, c.z, c.w);
+    return t;
+}
 // Out-of-range indices read as an all-zero record (the shader's robust-buffer behaviour).
 RT_DEV Tri load_tri_checked(const DScene &sc, int i) {
     if (i >= 0 && i < sc.count) return load_tri(sc.geo, i);

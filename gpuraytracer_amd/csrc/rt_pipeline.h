@@ -683,7 +683,7 @@ RT_DEV int closest_hit_list(const DScene &sc, const uint32_t *ids, uint32_t n, c
     const bool run = active & finite;
     for (uint32_t k = 1; k <= n; k++) {
         const int i = (int)((w[k >> 1] >> ((k & 1u) * 16u)) & 0xFFFFu);
-        const Tri t = load_tri(sc.geo, i);
+        const Tri t = load_tri_uniform(sc.geo, (uint32_t)i);
         // (measurement builds: a triangle test per lane with a ray, or the 64 lane slots of the wave's test)
 #if defined(RT_COUNT_WAVE_STEPS)
         cnt.tris += bvh_count_step();
