@@ -76,6 +76,9 @@ constexpr float INV_UINT_MAX_F = 1.0f / 4294967296.0f;
 struct DScene {
     const float4 *geo;
     const float4 *shade;
+    // LDS addresses (plain numbers, 0 = none) of a workgroup's copy of planes 0-3 of `shade` (what every hit reads) and of
+    // the material table: kernels of resident scenes stage them (stage_shading) and read them with LDS instructions
+    uint32_t shade_lds, mats_lds;
     const float4 *shade03;       // planes 0-3 of `shade` (what every hit reads): the same memory, or a workgroup's LDS copy of it
     const float4 *mats;          // 3 x float4 per material
     const int *has_tex;
@@ -217,10 +220,19 @@ struct ShadeRec {
 RT_DEV ShadeRec load_shade(const DScene &sc, int i) {
     ShadeRec r;
     if (i >= 0 && i < sc.count) {
-        const float4 a = sc.shade03[(size_t)0 * sc.count + i];
-        const float4 b = sc.shade03[(size_t)1 * sc.count + i];
-        const float4 c = sc.shade03[(size_t)2 * sc.count + i];
-        const float4 d = sc.shade03[(size_t)3 * sc.count + i];
+        float4 a, b, c, d;
+        if (sc.shade_lds) {
+            typedef const __attribute__((address_space(3))) v4f *lds_f4_ptr;
+            const lds_f4_ptr p = (lds_f4_ptr)(uintptr_t)sc.shade_lds;
+            const v4f va = p[0 * sc.count + i], vb = p[1 * sc.count + i], vc = p[2 * sc.count + i], vd = p[3 * sc.count + i];
+            a = make_float4(va.x, va.y, va.z, va.w); b = make_float4(vb.x, vb.y, vb.z, vb.w);
+            c = make_float4(vc.x, vc.y, vc.z, vc.w); d = make_float4(vd.x, vd.y, vd.z, vd.w);
+        } else {
+            a = sc.shade03[(size_t)0 * sc.count + i];
+            b = sc.shade03[(size_t)1 * sc.count + i];
+            c = sc.shade03[(size_t)2 * sc.count + i];
+            d = sc.shade03[(size_t)3 * sc.count + i];
+        }
         r.mat = __float_as_uint(a.w);
         r.n0 = mk3(a.x, a.y, a.z); r.n1 = mk3(b.x, b.y, b.z); r.n2 = mk3(c.x, c.y, c.z);
         r.tex_p[0] = b.w; r.tex_p[1] = c.w;
@@ -233,12 +245,22 @@ RT_DEV ShadeRec load_shade(const DScene &sc, int i) {
     return r;
 }
 
-struct Mat { f3 albedo, specular, emission; float roughness, ior; };
+struct Mat { f3 albedo, specular, emission; float roughness, ior; bool textured; };      // textured: hasTexture[m] == 1
 
 RT_DEV Mat load_mat(const DScene &sc, uint32_t m) {
     Mat r;
     if (m < (uint32_t)sc.n_mat) {
-        const float4 a = sc.mats[3 * m + 0], b = sc.mats[3 * m + 1], c = sc.mats[3 * m + 2];
+        float4 a, b, c;
+        if (sc.mats_lds) {
+            typedef const __attribute__((address_space(3))) v4f *lds_f4_ptr;
+            const lds_f4_ptr p = (lds_f4_ptr)(uintptr_t)sc.mats_lds;
+            const v4f va = p[3 * m + 0], vb = p[3 * m + 1], vc = p[3 * m + 2];
+            a = make_float4(va.x, va.y, va.z, va.w); b = make_float4(vb.x, vb.y, vb.z, vb.w); c = make_float4(vc.x, vc.y, vc.z, vc.w);
+            r.textured = __float_as_int(va.w) == 1;        // the LDS copy carries the flag in the record's unused word
+        } else {
+            a = sc.mats[3 * m + 0]; b = sc.mats[3 * m + 1]; c = sc.mats[3 * m + 2];
+            r.textured = sc.has_tex[m] == 1;
+        }
         r.albedo = mk3(a.x, a.y, a.z);
         r.specular = mk3(b.x, b.y, b.z);
         r.roughness = b.w;
@@ -247,6 +269,7 @@ RT_DEV Mat load_mat(const DScene &sc, uint32_t m) {
     } else {
         r.albedo = r.specular = r.emission = mk3(0.0f, 0.0f, 0.0f);
         r.roughness = r.ior = 0.0f;
+        r.textured = false;
     }
     return r;
 }
@@ -474,7 +497,7 @@ RT_DEV void shade_pre(const DScene &sc, const DFrame &fr, PathState &ps, int hit
     const ShadeRec tri = load_shade(sc, hit);
     const uint32_t mat_id = tri.mat;
     const Mat material = load_mat(sc, mat_id);
-    const bool has_texture = (mat_id < (uint32_t)sc.n_mat) && (sc.has_tex[mat_id] == 1);
+    const bool has_texture = material.textured;
 
     if (hit < sc.lights) ps.energy = ps.energy + ps.path * material.emission;               // :463-466
 

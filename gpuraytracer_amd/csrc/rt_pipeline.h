@@ -311,10 +311,19 @@ RT_DEV void stage_shading(DScene &sc, v4f *shade_mem) {
     if (!CFG::RES || CFG::SHADE_V4F <= 1) return;
     const int n_planes = 4 * sc.count, n_mats = 3 * sc.n_mat;
     for (int i = threadIdx.x; i < n_planes; i += blockDim.x) shade_mem[i] = ((const v4f *)sc.shade)[i];
-    for (int i = threadIdx.x; i < n_mats; i += blockDim.x) shade_mem[n_planes + i] = ((const v4f *)sc.mats)[i];
+    for (int i = threadIdx.x; i < n_mats; i += blockDim.x) {
+        v4f rec = ((const v4f *)sc.mats)[i];
+        // the first of a material's three words has an unused component: it carries hasTexture[m] in the LDS copy, so that a
+        // shaded lane needs no read from memory to know whether its material is textured
+        if (i % 3 == 0) rec.w = __int_as_float(sc.has_tex[i / 3]);
+        shade_mem[n_planes + i] = rec;
+    }
     __syncthreads();
-    sc.shade03 = (const float4 *)shade_mem;
-    sc.mats = (const float4 *)(shade_mem + n_planes);
+    // (as plain numbers in scalar registers: left as "start of the array + offset" every read would add the start again)
+    uint32_t at = (uint32_t)(uintptr_t)(lds_v4f_ptr)shade_mem;
+    asm volatile("" : "+s"(at));
+    sc.shade_lds = at;
+    sc.mats_lds = at + 16u * (uint32_t)n_planes;
 }
 
 // The three searches of a bounce in the form the kernel's configuration selects.
