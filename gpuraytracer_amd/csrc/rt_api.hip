@@ -130,6 +130,7 @@ DScene device_scene(const rt_context *ctx) {
     sc.shade03 = ctx->d_shade;
     sc.shade_lds = 0;
     sc.mats_lds = 0;
+    sc.light_geo_lds = 0;
     sc.mats = ctx->d_mats;
     sc.has_tex = ctx->d_has_tex;
     sc.atlas = ctx->d_atlas_ptrs;

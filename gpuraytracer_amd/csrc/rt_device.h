@@ -79,6 +79,7 @@ struct DScene {
     // LDS addresses (plain numbers, 0 = none) of a workgroup's copy of planes 0-3 of `shade` (what every hit reads) and of
     // the material table: kernels of resident scenes stage them (stage_shading) and read them with LDS instructions
     uint32_t shade_lds, mats_lds;
+    uint32_t light_geo_lds;      // the same for the geometry records of the emissive triangles (the first `lights` ones), 0 = none
     const float4 *shade03;       // planes 0-3 of `shade` (what every hit reads): the same memory, or a workgroup's LDS copy of it
     const float4 *mats;          // 3 x float4 per material
     const int *has_tex;
@@ -157,6 +158,17 @@ RT_DEV Tri load_tri_uniform(const float4 *geo, uint32_t i) {
 }
 // Out-of-range indices read as an all-zero record (the shader's robust-buffer behaviour).
 RT_DEV Tri load_tri_checked(const DScene &sc, int i) {
+    if (sc.light_geo_lds && i >= 0 && i < sc.lights && i < sc.count) {
+        typedef const __attribute__((address_space(3))) v4f *lds_f4_ptr;
+        const lds_f4_ptr g = (lds_f4_ptr)(uintptr_t)sc.light_geo_lds;
+        const v4f a = g[3 * i + 0], b = g[3 * i + 1], c = g[3 * i + 2];
+        Tri t;
+        t.n = mk3(a.x, a.y, a.z);
+        t.p = mk3(a.w, b.x, b.y);
+        t.u = mk3(b.z, b.w, c.x);
+        t.v = mk3(c.y, c.z, c.w);
+        return t;
+    }
     if (i >= 0 && i < sc.count) return load_tri(sc.geo, i);
     Tri t;
     t.n = t.p = t.u = t.v = mk3(0.0f, 0.0f, 0.0f);

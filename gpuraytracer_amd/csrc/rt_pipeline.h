@@ -318,12 +318,19 @@ RT_DEV void stage_shading(DScene &sc, v4f *shade_mem) {
         if (i % 3 == 0) rec.w = __int_as_float(sc.has_tex[i / 3]);
         shade_mem[n_planes + i] = rec;
     }
+    // the geometry of the emissive triangles too, if there is room left: sampleLight reads one of them per bounce, per
+    // lane from the second bounce on
+    const int n_light_geo = 3 * (sc.lights < sc.count ? sc.lights : sc.count);
+    const bool light_geo = n_light_geo > 0 && n_planes + n_mats + n_light_geo <= CFG::SHADE_V4F;
+    if (light_geo)
+        for (int i = threadIdx.x; i < n_light_geo; i += blockDim.x) shade_mem[n_planes + n_mats + i] = ((const v4f *)sc.geo)[i];
     __syncthreads();
     // (as plain numbers in scalar registers: left as "start of the array + offset" every read would add the start again)
     uint32_t at = (uint32_t)(uintptr_t)(lds_v4f_ptr)shade_mem;
     asm volatile("" : "+s"(at));
     sc.shade_lds = at;
     sc.mats_lds = at + 16u * (uint32_t)n_planes;
+    if (light_geo) sc.light_geo_lds = at + 16u * (uint32_t)(n_planes + n_mats);
 }
 
 // The three searches of a bounce in the form the kernel's configuration selects.
