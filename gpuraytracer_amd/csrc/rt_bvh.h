@@ -524,8 +524,10 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
         return true;
     };
     auto limit = [&]() -> float { return lim; };
+    bool handed_over = false;       // wave-uniform: some lane of this wave searches for another lane's query
     for (;;) {
-        if (ts.run && flags[owner] != 0) ts.run = false;          // another helper of this query has found a hit
+        // another helper of this query has found a hit (nobody has a helper before the first hand-over: no flag to read)
+        if (handed_over && ts.run && flags[owner] != 0) ts.run = false;
         const unsigned long long running = __builtin_amdgcn_ballot_w64(ts.run);
         if (running == 0ull) break;
         const unsigned long long donors = __builtin_amdgcn_ballot_w64(ts.run && ts.sp > 1);
@@ -535,6 +537,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
             const unsigned long long idle = ~running;
             const int d_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(donors >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donors, 0u));
             const int i_rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            handed_over = true;
             const bool gives = ts.run && ts.sp > 1 && d_rank < n_take;
             const bool takes = !ts.run && i_rank < n_take;
             if (gives) table[d_rank] = (unsigned char)lane;
