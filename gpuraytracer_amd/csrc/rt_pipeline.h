@@ -308,7 +308,10 @@ constexpr int LDS_SHADE_V4F = RT_LDS_SHADE_KB * 64;
 inline bool shading_fits_lds(int count, int n_mat) { return LDS_SHADE_V4F <= 1 || 4 * (long long)count + 3 * (long long)n_mat <= LDS_SHADE_V4F; }
 template <class CFG>
 RT_DEV void stage_shading(DScene &sc, v4f *shade_mem) {
-    if (!CFG::RES || CFG::SHADE_V4F <= 1) return;
+    if (!CFG::RES || CFG::SHADE_V4F <= 1) {
+        sc.shade_lds = sc.mats_lds = sc.light_geo_lds = 0u;      // (known to the compiler from here on: no LDS form of these reads in this kernel)
+        return;
+    }
     const int n_planes = 4 * sc.count, n_mats = 3 * sc.n_mat;
     for (int i = threadIdx.x; i < n_planes; i += blockDim.x) shade_mem[i] = ((const v4f *)sc.shade)[i];
     for (int i = threadIdx.x; i < n_mats; i += blockDim.x) {
@@ -328,6 +331,7 @@ RT_DEV void stage_shading(DScene &sc, v4f *shade_mem) {
     // (as plain numbers in scalar registers: left as "start of the array + offset" every read would add the start again)
     uint32_t at = (uint32_t)(uintptr_t)(lds_v4f_ptr)shade_mem;
     asm volatile("" : "+s"(at));
+    __builtin_assume(at != 0u);        // (the memory form of these reads is not compiled into this kernel)
     sc.shade_lds = at;
     sc.mats_lds = at + 16u * (uint32_t)n_planes;
     if (light_geo) sc.light_geo_lds = at + 16u * (uint32_t)(n_planes + n_mats);
@@ -1641,17 +1645,21 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
 
 // Resolve stage: sum[pixel] += radiance of the batch's samples, ascending slot order.  SKIP: samples whose radiance is
 // not finite are counted and left out (option "skip_nonfinite"; the reference adds them, which poisons the pixel).
+// A wave takes one 8x8 tile, thread = position in the radiance plane: per slot it reads 768 consecutive bytes (threads
+// in raster order read eight pieces of 96 bytes, each straddling cache lines that other waves fetch again).
 template <bool SKIP>
 __global__ __launch_bounds__(256) void k_resolve(PipeBuffers b, float4 *__restrict__ sum, uint32_t width,
                                                  uint32_t height, uint32_t paths_per_sample, uint32_t n_slots,
                                                  DStats *__restrict__ stats) {
-    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_image = pix < width * height;
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tiles_x = (width + 7u) >> 3, tiles_y = (height + 7u) >> 3;
+    uint32_t tile_x, tile_y;
+    tile_position(local >> 6, tiles_x, tiles_y, tile_x, tile_y);
+    const uint32_t tx = tile_x * 8u + (threadIdx.x & 7u), ty = tile_y * 8u + ((threadIdx.x >> 3) & 7u);
+    const bool in_image = local < paths_per_sample && tx < width && ty < height;
     uint32_t skipped = 0;
     if (in_image) {
-        const uint32_t tx = pix % width, ty = pix / width;
-        const uint32_t tiles_x = (width + 7u) >> 3, tiles_y = (height + 7u) >> 3;
-        const uint32_t local = tile_number(tx >> 3, ty >> 3, tiles_x, tiles_y) * 64u + (ty & 7u) * 8u + (tx & 7u);
+        const uint32_t pix = ty * width + tx;
         float4 s = sum[pix];
         for (uint32_t k = 0; k < n_slots; k++) {
             const Radiance e = b.energy[(size_t)k * paths_per_sample + local];
@@ -1930,10 +1938,10 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
         }
     }
     if (fr.skip_nonfinite)
-        hipLaunchKernelGGL(k_resolve<true>, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
+        hipLaunchKernelGGL(k_resolve<true>, dim3((pps + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
                            fr.height, pps, tab.n, dstats);
     else
-        hipLaunchKernelGGL(k_resolve<false>, dim3((fr.width * fr.height + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
+        hipLaunchKernelGGL(k_resolve<false>, dim3((pps + 255u) / 256u), dim3(256), 0, stream, buf, sum, fr.width,
                            fr.height, pps, tab.n, dstats);
     PIPE_TRY(hipGetLastError());
 #undef PIPE_TRY
