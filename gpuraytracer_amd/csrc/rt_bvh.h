@@ -313,6 +313,12 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
                 const float n0y = py[0], f0y = py[1], n1y = py[3], f1y = py[4];
                 const float n0z = pz[0], f0z = pz[1], n1z = pz[3], f1z = pz[4];
                 c0 = links[0]; c1 = links[1];
+#ifdef RT_EXTRA_LDS
+                {   // measurement build: two more 8-byte LDS reads per node step, results unused (is the LDS pipe what limits the step?)
+                    typedef volatile __attribute__((address_space(3))) unsigned long long *lds_v64_ptr;
+                    (void)*(lds_v64_ptr)(rec + 0); (void)*(lds_v64_ptr)(rec + 24);
+                }
+#endif
                 in0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(n0x, br.inv.x, -br.ca.x), __builtin_fmaf(n0y, br.inv.y, -br.ca.y)),
                                                       __builtin_fmaf(n0z, br.inv.z, -br.ca.z)), 0.0f);
                 out0 = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaf(f0x, br.inv.x, -br.cb.x), __builtin_fmaf(f0y, br.inv.y, -br.cb.y)),

@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
                 shaded = true;
             }
         }
-        SECTION_MARK(1);
+        SECTION_MARK(RT_SECTION_CLOCKS == 4 ? 0 : 1);         // 4: closest hit and shading booked together, the slot goes to parking / taking up
         Ray probe; probe.o = ps.o; probe.d = bn.probe_d;
         float probe_max_t = bn.max_t;
         ps.kept_diff = ps.kept_spec = mk3(0.0f, 0.0f, 0.0f);
@@ -1180,6 +1180,9 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
             }
         }
         const bool run = (wants && !parked) || host;
+#if RT_SECTION_CLOCKS == 4
+        SECTION_MARK(1);
+#endif
 #if RT_PROBE_HISTO > 0
         // measurement build: searches of the depth-0 kernel by the number of lanes they run with (1: shadow, 2: glossy)
         if (RT_PROBE_HISTO < 3 && (RT_PROBE_HISTO == 1) == coin_diffuse) {
