@@ -283,7 +283,11 @@ RT_DEV void trav_begin(const WS &ws, TravState &ts, bool run) {
 // "while-while" order: all lanes first descend through inner nodes until each holds a leaf (or has finished),
 // then all leaves are processed together; this keeps box tests and triangle tests of a wave from
 // interleaving lane by lane.
-template <bool BUDGETED = false, class WS, typename LeafFn, typename LimitFn>
+// LOOP_SHARE > 0: a round's node loop ends as soon as fewer than 1 / LOOP_SHARE of the running lanes still descend; the
+// others' leaves are tested first and the stragglers go on in the next round.  Pays where a node step waits for memory
+// (1 M triangles: the lane-refill extend kernel -20 %, the pass +3.9 %); where the nodes are in LDS the test itself, four
+// instructions per step, costs more than the shorter loops save (424 triangles -5 %, 12 030 triangles -3 %).
+template <bool BUDGETED = false, int LOOP_SHARE = 0, class WS, typename LeafFn, typename LimitFn>
 RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravState &ts, int stop_at, LeafFn leaf,
                         LimitFn t_limit, BvhCounters &cnt, bool at_least_one = false, int node_budget = 1 << 30) {
     int *stack = ws.stack;
@@ -295,6 +299,7 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
         if (running == 0ull || (!at_least_one && 64 - (int)__popcll(running) >= stop_at)) break;
         // a divergent loop: lanes leave as they reach a leaf or finish, and the wave goes on when none is left
         int budget = node_budget;
+        const int n_running = (int)__popcll(running);
         // the first free entry of the lane's stack as an LDS address (entries of a lane are 64 apart): a step then needs no
         // multiplication for its accesses
         typedef __attribute__((address_space(3))) int *lds_stack_ptr;
@@ -367,9 +372,11 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
             int next = near;
             if (pop) next = *top;
             node = next;
+            // the lanes that still descend have become few: the others' leaves first, these go on in the next round
+            if (LOOP_SHARE > 0 && LOOP_SHARE * (int)__popcll(__builtin_amdgcn_ballot_w64(node >= 0)) < n_running) break;
         }
         sp = (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)(lds_stack_ptr)stack) >> 8);
-        if (run && (!BUDGETED || node < 0)) {      // a leaf
+        if (run && (!(BUDGETED || LOOP_SHARE > 0) || node < 0)) {      // a leaf
             const int code = ~node;
             const int first = code >> 3, n = code & 7;
             bool go_on = true;
@@ -391,12 +398,12 @@ RT_DEV void bvh_advance(const DBvh &bv, const BvhRay &br, const WS &ws, TravStat
 }
 
 // One traversal from the root to the end for the lanes with `active`.
-template <class WS, typename LeafFn, typename LimitFn>
+template <int LOOP_SHARE = 0, class WS, typename LeafFn, typename LimitFn>
 RT_DEV void bvh_traverse(const DBvh &bv, const BvhRay &br, bool active, const WS &ws, LeafFn leaf, LimitFn t_limit,
                          BvhCounters &cnt) {
     TravState ts;
     trav_begin(ws, ts, active);
-    bvh_advance(bv, br, ws, ts, 65, leaf, t_limit, cnt);
+    bvh_advance<false, LOOP_SHARE>(bv, br, ws, ts, 65, leaf, t_limit, cnt);
 }
 
 // The triangle record of a leaf slot (3 of the 4 float4 of the slot).  Its index is the first word of the
@@ -483,7 +490,7 @@ RT_DEV void closest_fold_redo(const DScene &sc, const Ray &ray, bool redo, int b
 // restricts the triangles considered (the glossy probe folds over the light triangles only),
 // `current` is skipped.  Returns the triangle id or -1; isec = (x, y, rd, det) of the winner, or
 // (0, 0, -1, w_init) when nothing was hit.
-template <class WS>
+template <int LOOP_SHARE = 0, class WS>
 RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, int begin_id, int end_id,
                            int current, float w_init, const WS &ws, f4 &isec, BvhCounters &cnt) {
     const BvhRay br = bvh_ray_setup<WS::RES>(ray, bv, ws);
@@ -491,7 +498,7 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
     closest_fold_reset(cf, w_init);
     auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, current, cf); return true; };
     auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
-    bvh_traverse(bv, br, active && br.finite, ws, leaf, limit, cnt);
+    bvh_traverse<LOOP_SHARE>(bv, br, active && br.finite, ws, leaf, limit, cnt);
     closest_fold_redo(sc, ray, active && (!br.finite || cf.n_near > 2), begin_id, end_id, current, w_init, cf);
     isec = cf.st;
     return cf.best;
@@ -510,6 +517,9 @@ constexpr int SHARE_MIN_IDLE = RT_SHARE_MIN_IDLE;
 // NODE_BUDGET > 0: at most that many node steps per lane between two looks for idle lanes.  Long traversals gain
 // (1 M triangles: +8 % with 4), short ones lose the bookkeeping (424 triangles: -2.5 %), so the host picks by scene size.
 constexpr int SHARE_NODE_BUDGET = 4;
+#ifndef RT_ANYHIT_LOOP_SHARE
+#define RT_ANYHIT_LOOP_SHARE 0
+#endif
 constexpr int SHARE_BUDGET_MIN_TRIANGLES = 4096;
 typedef volatile __attribute__((address_space(3))) unsigned char *lds_u8_ptr;
 
@@ -569,7 +579,7 @@ RT_DEV bool anyhit_shared(const DBvh &bv, const WS &ws, lds_u8_ptr scratch, Ray 
                 ts.node = t_node; ts.sp = 1; ts.run = true;
             }
         }
-        bvh_advance<(NODE_BUDGET > 0)>(bv, br, ws, ts, SHARE_MIN_IDLE, leaf, limit, cnt, true, NODE_BUDGET > 0 ? NODE_BUDGET : 1 << 30);
+        bvh_advance<(NODE_BUDGET > 0), (NODE_BUDGET > 0 ? RT_ANYHIT_LOOP_SHARE : 0)>(bv, br, ws, ts, SHARE_MIN_IDLE, leaf, limit, cnt, true, NODE_BUDGET > 0 ? NODE_BUDGET : 1 << 30);
     }
     return flags[lane] != 0;
 }

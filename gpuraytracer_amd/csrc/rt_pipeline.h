@@ -337,12 +337,22 @@ RT_DEV void stage_shading(DScene &sc, v4f *shade_mem) {
     if (light_geo) sc.light_geo_lds = at + 16u * (uint32_t)(n_planes + n_mats);
 }
 
+// Closest-hit searches of large scenes (the configurations with a node-step budget) leave a round's node loop when fewer
+// than this share of the running lanes still descend (see bvh_advance); 0: never.
+#ifndef RT_LARGE_LOOP_SHARE
+#define RT_LARGE_LOOP_SHARE 4
+#endif
+#ifndef RT_REFILL_LOOP_SHARE
+#define RT_REFILL_LOOP_SHARE 4
+#endif
+constexpr int LARGE_LOOP_SHARE = RT_LARGE_LOOP_SHARE, REFILL_LOOP_SHARE = RT_REFILL_LOOP_SHARE;
+
 // The three searches of a bounce in the form the kernel's configuration selects.
 template <class CFG>
 RT_DEV int closest_hit_cfg(const DScene &sc, const DBvh &bv, const Ray &ray, bool active, const typename CFG::WS &ws, f4 &isec,
                            BvhCounters &cnt) {
     SearchPriority prio;
-    if (CFG::BVH) return closest_hit_bvh(sc, bv, ray, active, 0, sc.count, -1, 1.0f, ws, isec, cnt);
+    if (CFG::BVH) return closest_hit_bvh<(CFG::NODE_BUDGET > 0 ? LARGE_LOOP_SHARE : 0)>(sc, bv, ray, active, 0, sc.count, -1, 1.0f, ws, isec, cnt);
     return closest_hit_bf(sc, ray, isec);
 }
 template <class CFG>
@@ -1632,7 +1642,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
         if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
         auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, -1, cf); return true; };
         auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
-        bvh_advance(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
+        bvh_advance<false, REFILL_LOOP_SHARE>(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
         const bool fin = busy && !ts.run;
         closest_fold_redo(sc, ray, fin && (!br.finite || cf.n_near > 2), 0, sc.count, -1, 1.0f, cf);
         if (fin) {
