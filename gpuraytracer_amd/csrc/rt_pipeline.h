@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
             ts.node = ws.root; ts.sp = 1; ts.run = br.finite;
         }
         if (__builtin_amdgcn_ballot_w64(busy) == 0ull) break;
-        auto leaf = [&](int slot) -> bool { closest_fold_leaf(bv, ws, ray, slot, -1, cf); return true; };
+        auto leaf = [&](int slot, const Tri &t, int id_ahead) -> bool { closest_fold_leaf(bv, ws, ray, slot, t, id_ahead, -1, cf); return true; };
         auto limit = [&]() -> float { return cf.t_min * BVH_NEAR; };
         bvh_advance<false, REFILL_LOOP_SHARE>(bv, br, ws, ts, next < total ? REFILL_MIN : 65, leaf, limit, bc);
         const bool fin = busy && !ts.run;
