@@ -545,7 +545,10 @@ RT_DEV int closest_hit_bvh(const DScene &sc, const DBvh &bv, const Ray &ray, boo
 constexpr int SHARE_MIN_IDLE = RT_SHARE_MIN_IDLE;
 // NODE_BUDGET > 0: at most that many node steps per lane between two looks for idle lanes.  Long traversals gain
 // (1 M triangles: +8 % with 4), short ones lose the bookkeeping (424 triangles: -2.5 %), so the host picks by scene size.
-constexpr int SHARE_NODE_BUDGET = 4;
+#ifndef RT_SHARE_NODE_BUDGET
+#define RT_SHARE_NODE_BUDGET 4
+#endif
+constexpr int SHARE_NODE_BUDGET = RT_SHARE_NODE_BUDGET;
 #ifndef RT_ANYHIT_LOOP_SHARE
 #define RT_ANYHIT_LOOP_SHARE 0
 #endif

@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::BVH ? RT_MIN_WAVES : 1) void k_
 // not depend on which lane or in which order it is processed, and the order of a queue region only
 // decides the order of the next region, so results stay bit-identical.
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 24
+#define RT_REFILL_MIN 32
 #endif
 constexpr int REFILL_MIN = RT_REFILL_MIN;
 
