@@ -333,6 +333,21 @@ int rt_create(int device, rt_context **out) {
     }
     ctx->stream = ctx->own_stream;
     lookup_scratch(device);
+    // The kernels are gfx950 code and their work distribution (PIPE_WAVES persistent waves, N_XCD, one workgroup per
+    // compute unit) is laid out for a whole MI355X of 256 compute units.  Another architecture cannot run them; a
+    // partition of the chip can, with the same results (no wave waits for another), but not at the documented rates:
+    // that is said once, where rt_last_error() finds it.
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        (void)rt_destroy(ctx);
+        return RT_ERR_DEVICE;
+    }
+    if (prop.multiProcessorCount != PIPE_WAVES / RT_WAVES_PER_CU) {
+        char note[160];
+        snprintf(note, sizeof(note), "note: device %d has %d compute units; the work distribution is laid out for %d (results are the same)",
+                 device, prop.multiProcessorCount, PIPE_WAVES / RT_WAVES_PER_CU);
+        ctx->err = note;
+    }
     *out = ctx;
     return RT_OK;
 }

@@ -94,6 +94,9 @@ typedef struct rt_context rt_context;
 /* Lifetime.  `device` is the HIP device ordinal.  Scene::Scene / Scene::~Scene
  * (Scene.cpp:231-280) own every GL object in the reference; the context owns every
  * device allocation here. */
+/* rt_create refuses (RT_ERR_DEVICE) a device that is not gfx950.  On a device with another number of compute units than
+ * the 256 the work distribution is laid out for (a partition of the chip), it succeeds and leaves a note that starts
+ * with "note:" for rt_last_error(); results do not depend on it. */
 int rt_create(int device, rt_context **out);
 int rt_destroy(rt_context *ctx);
 const char *rt_last_error(const rt_context *ctx);

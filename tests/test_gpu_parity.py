@@ -672,6 +672,8 @@ def test_error_behaviour(oracle_mod, cubes):
     import gpuraytracer_amd as g
     ctx = g.Context(0)
     try:
+        # a whole MI355X (256 compute units) is what the work distribution is laid out for: no note about the device
+        assert ctx.lib.rt_last_error(ctx.h).decode() == ""
         with pytest.raises(g.GpuRtError):       # no scene yet
             ctx.trace(0, 1, 1)
         models, shadings, lights, materials = cubes
