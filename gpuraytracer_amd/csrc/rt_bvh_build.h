@@ -67,7 +67,10 @@ struct Item { Box box; float c[3]; int32_t id; };
 #ifndef RT_LARGE_LEAF
 #define RT_LARGE_LEAF 2
 #endif
-inline int max_leaf_for(uint32_t count) { return count >= 65536u ? RT_LARGE_LEAF : (count < 2048u ? RT_SMALL_LEAF : 3); }
+#ifndef RT_MID_LEAF
+#define RT_MID_LEAF 3
+#endif
+inline int max_leaf_for(uint32_t count) { return count >= 65536u ? RT_LARGE_LEAF : (count < 2048u ? RT_SMALL_LEAF : RT_MID_LEAF); }
 #ifndef RT_BVH_BINS
 #define RT_BVH_BINS 32
 #endif
