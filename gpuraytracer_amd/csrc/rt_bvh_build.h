@@ -389,11 +389,8 @@ inline void quantise_nodes(HostBvh &b) {
     }
 }
 
-#ifndef RT_MEDIAN_FROM
-#define RT_MEDIAN_FROM 0xFFFFFFFFu      // measurement builds: scenes from this many triangles on are split by object median only
-#endif
 inline void build_bvh(const rt_triangle_model *tris, uint32_t count, HostBvh &out) {
-    build_bvh_impl(tris, count, count >= RT_MEDIAN_FROM, out);
+    build_bvh_impl(tris, count, false, out);
     if (out.depth >= BVH_STACK_DEPTH - 2) build_bvh_impl(tris, count, true, out);
     reorder_breadth_first(out);
     quantise_nodes(out);

@@ -1404,9 +1404,6 @@ __global__ __launch_bounds__(64 * WG_WAVES, RT_MIN_WAVES) void k_tail(DScene sc,
 }
 
 // Shading of the paths whose hit records the lane-refill form of the extend stage has left in h0.
-#ifndef RT_SHADE_AHEAD
-#define RT_SHADE_AHEAD 0
-#endif
 __global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, PipeBuffers b, int depth, int q_in, PassTables tab,
                                                          uint32_t paths_per_sample, int max_depth) {
     if (round_is_idle(b.work, b.round)) return;
@@ -1415,25 +1412,14 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_shade(DScene sc, DFrame fr, P
     const size_t region = (size_t)wave * b.region_cap;
     RouteFill fill;
     fill.shadow = fill.glossy = fill.next = 0;
-    // the records of a block are asked for while the block before it is shaded (RT_SHADE_AHEAD)
-    float4 rec_a, rec_b, rec_c, rec_h;
-    uint4 rec_d;
-    auto ask = [&](uint32_t base) {
-        const uint32_t qi = base + lane;
-        const size_t hi = region + (qi < total ? qi : 0u);
-        rec_a = b.xa[q_in][hi]; rec_b = b.xb[q_in][hi]; rec_c = b.xc[q_in][hi]; rec_d = b.xd[q_in][hi];
-        rec_h = b.h0[hi];
-    };
-    if (RT_SHADE_AHEAD && total != 0u) ask(0u);
     for (uint32_t base = 0; base < total; base += 64u) {
-        if (!RT_SHADE_AHEAD) ask(base);
-        const bool live = base + lane < total;
+        const uint32_t qi = base + lane;
+        const bool live = qi < total;
+        uint32_t id = 0, kept_flags = 0;
         PathState ps;
-        unpack_path(rec_a, rec_b, rec_c, ps);
-        ps.seed = rec_d.x;
-        const uint32_t id = rec_d.y, kept_flags = rec_d.z;
-        const float4 h = rec_h;
-        if (RT_SHADE_AHEAD && base + 64u < total) ask(base + 64u);
+        const size_t hi = region + (live ? qi : 0u);
+        load_path_rec(b, q_in, hi, ps, id, kept_flags);
+        const float4 h = b.h0[hi];
         shade_and_route(sc, fr, b, depth, q_in, tab, paths_per_sample, max_depth, live, id, ps, kept_flags,
                         __float_as_int(h.w), h.x, h.y, h.z, fill);
     }
