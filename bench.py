@@ -82,22 +82,34 @@ def kernel_source_fingerprint():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(scene, cam, clock, recursion, budget_s=12.0):
+def cpu_baseline(scene, cam, clock, recursion, budget_s=12.0, size=None, layers=None, atlas=0):
     """The CPU restatement (oracle/, C-library math, OpenMP) on a bounded sample of the same workload:
-    whole frames of consecutive SAMPLE indices, as many as fit the time budget."""
+    whole frames of consecutive SAMPLE indices, as many as fit the time budget.  `size`: a smaller target for the same
+    camera (the restatement loops over all triangles per query as the reference does: on a million triangles a 1080p
+    frame takes minutes); `layers`: the texture layers of the c3 workload."""
     from oracle import oracle
+    w, h = size if size else (W, H)
     sc = oracle.OracleScene(*scene, libm=True)
     sc.upload_env(constant_env())
+    if layers is not None:
+        sc.set_atlas_size(atlas)
+        flags = np.zeros(len(scene[3]), dtype=np.int32)
+        for m in (0, 1):
+            for k in range(3):
+                sc.upload_atlas_layer(m, k, layers[k])
+            flags[m] = 1
+        sc.set_has_texture(flags)
     t0 = time.perf_counter()
-    _, st = sc.render(cam, clock, recursion, 1.0, W, H, 0, 1)
+    _, st = sc.render(cam, clock, recursion, 1.0, w, h, 0, 1)
     t1 = time.perf_counter() - t0
     spp = int(max(1, min(32, budget_s / max(t1, 1e-3))))
     t0 = time.perf_counter()
-    _, st = sc.render(cam, clock, recursion, 1.0, W, H, 0, spp)
+    _, st = sc.render(cam, clock, recursion, 1.0, w, h, 0, spp)
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%dx%d, SAMPLE 0..%d (%d rays) in %.2f s, OpenMP over pixels" % (W, H, spp - 1, st["rays"], dt)}
+            "sample": "%dx%d%s, SAMPLE 0..%d (%d rays) in %.2f s, OpenMP over pixels"
+                      % (w, h, "" if not size else " (the camera of the %dx%d workload on a smaller target)" % (W, H), spp - 1, st["rays"], dt)}
 
 
 def llvmpipe_baseline():
@@ -251,6 +263,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     scene, cam, RECURSION, workload_name, layers = load_workload(g, args)
+    cpu_layers = None
     clock = g.DEFAULT_CLOCK
     strong = not args.weak
     if strong:
@@ -295,6 +308,7 @@ def main():
                 ctx.upload_atlas_layer(m, k, layers[k])
             flags[m] = 1
         ctx.set_has_texture(flags)
+        cpu_layers = layers if not args.no_cpu_baseline else None       # (the CPU baseline of this workload samples them too)
         layers = None
     ctx.upload_env(constant_env())
     ctx.resize(W, H)
@@ -410,11 +424,11 @@ def main():
             # ray, counted by the measurement build of the library in a depth-0-only render) over the lane-operations the chip
             # could have issued in the launch time.  Idle lanes of a wave, bookkeeping and waiting are what is missing to 1.
             useful = None
-            want_lanes = args.lane_utilisation != 0 and world == 1 and args.workload in ("cubes", "obiwan")
+            want_lanes = args.lane_utilisation != 0 and world == 1
             if want_lanes and launch_s > 0:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import lane_utilisation
-                first = lane_utilisation.measure(args.workload, 1)         # RECURSION 1: the depth-0 kernel alone
+                first = lane_utilisation.measure(args.workload, 1, args.grid, args.atlas)         # RECURSION 1: the depth-0 kernel alone
                 resident = args.workload == "cubes" and args.resident != 0
                 n_node = INSTS_NODE_RESIDENT if resident else INSTS_NODE_MEMORY
                 scale = (float(st["pixel_samples"]) / ext_n) / float(first["pixel_samples"])      # a launch against the 32 spp counted
@@ -437,7 +451,8 @@ def main():
                     useful["other_lane_ops_per_launch_upper"] = other
                     useful["with_shading_upper_frac"] = (lane_ops + other) / peak_ops
             frac = useful["with_shading_upper_frac"] if useful and "with_shading_upper_frac" in useful else (useful["traversal_frac"] if useful else None)
-            if frac is not None:
+            # (the 1 M-triangle workload keeps the memory side as its headline: its kernel waits for records, useful.* is beside it)
+            if frac is not None and args.workload != "c3":
                 roof = {"bound": "valu", "kernel": kernel_name,
                         "achieved": frac * PEAK_LANE_TOPS, "peak": PEAK_LANE_TOPS, "unit": "TFLOP/s", "frac": frac,
                         "traffic": traffic,
@@ -455,9 +470,9 @@ def main():
                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                         "traffic": traffic,
                         "traffic_source": provenance if comparable else "not measured for this configuration (%s)" % provenance,
-                        "note": "no traversal step counts for this configuration (they need the measurement builds and a bundled "
-                                "scene): algorithmic bytes against HBM; the kernel waits for node and leaf records that miss "
-                                "LDS and L1 (memory_path, valu_issue)" if args.workload == "c3" else
+                        "note": "algorithmic bytes against HBM; the kernel waits for node and leaf records that miss LDS and L1 "
+                                "(memory_path: L2 rate and hit rate, vector memory busy; valu_issue: what it issues; useful: the share "
+                                "of the chip's lane operations that is traversal work of the rays themselves)" if args.workload == "c3" else
                                 "traversal step counts were not collected in this run (--lane-utilisation 0, another target size "
                                 "or more than one rank): algorithmic bytes against HBM, which is not what bounds this kernel; the "
                                 "default single-GPU line reports bound valu with the useful-work fraction"}
@@ -539,10 +554,13 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import lane_utilisation
             out["lane_utilisation"] = lane_utilisation.measure(args.workload, RECURSION)
-        if args.workload == "c3":
-            # the CPU restatement loops over all triangles per query as the reference does: hours per frame here
-            out["cpu_baseline"] = None
-        elif not args.no_cpu_baseline and world == 1:
+        if args.no_cpu_baseline or world != 1:
+            pass
+        elif args.workload == "c3":
+            # the CPU restatement loops over all triangles per query as the reference does: a 1080p frame of this scene takes
+            # minutes, so the bounded sample is the same camera on a target of 1/12 the width and height
+            out["cpu_baseline"] = cpu_baseline(scene, cam, clock, RECURSION, size=(W // 12, H // 12), layers=cpu_layers, atlas=args.atlas)
+        else:
             out["cpu_baseline"] = cpu_baseline(scene, cam, clock, RECURSION)
         if args.workload == "cubes":
             out["cpu_baseline_llvmpipe"] = llvmpipe_baseline()
