@@ -256,11 +256,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # GPURT_BENCH_SHARED_GPU=1: a rehearsal of the multi-rank path where there are fewer GPUs than ranks (the ranks share
+    # the devices there are and talk over gloo; RCCL refuses two ranks on one device).  It exercises the launcher, the sample
+    # split, the ordered reduce and the rank-0 line on hardware; its rate says nothing about scaling.
+    shared_gpu = os.environ.get("GPURT_BENCH_SHARED_GPU") == "1"
+    device = local_rank % max(1, torch.cuda.device_count()) if shared_gpu else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1 or "RANK" in os.environ:     # under torch.distributed.run also with one rank (exercises the RCCL path)
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
 
     scene, cam, RECURSION, workload_name, layers = load_workload(g, args)
     cpu_layers = None
@@ -280,7 +288,7 @@ def main():
     steps = len(plan)
     my_count = sum(n for _, n, _ in plan)
 
-    ctx = g.Context(local_rank)
+    ctx = g.Context(device)
     ctx.set_option("pipeline", args.pipeline)
     ctx.set_option("batch_samples", args.batch_samples)
     ctx.set_option("accel", args.accel)
@@ -350,7 +358,7 @@ def main():
 
     st = ctx.stats()
     tot = torch.tensor([float(st["rays"]), float(st["shadow_probes"] + st["glossy_probes"]), dt, reduce_ms, float(my_count)],
-                       dtype=torch.float64, device="cuda")
+                       dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)

@@ -44,6 +44,13 @@ def reduce_sums(tensor, dst=0, group=None, ordered=True):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
         return tensor
+    if tensor.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo does not gather device tensors: the buffers go through host memory (CPU tests and shared-GPU rehearsals)
+        host = tensor.cpu()
+        reduce_sums(host, dst=dst, group=group, ordered=ordered)
+        if dist.get_rank(group) == dst:
+            tensor.copy_(host)
+        return tensor
     if not ordered:
         dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM, group=group)
         return tensor
