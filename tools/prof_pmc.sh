@@ -9,5 +9,5 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc $COUNTERS --output-format csv -d $OUT -- python3 $R/bench.py --steps 1 --warmup 1 --spp-per-step 512 --no-cpu-baseline --no-bruteforce-pass "$@" > $OUT/run.log 2>&1
+timeout -s KILL 400 rocprofv3 --pmc $COUNTERS --output-format csv -d $OUT -- python3 $R/bench.py --steps 1 --warmup 1 --spp-per-step 512 --no-cpu-baseline --no-bruteforce-pass "$@" > $OUT/run.log 2>&1
 find $OUT -name "*counter_collection.csv" | head -2
