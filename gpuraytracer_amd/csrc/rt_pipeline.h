@@ -113,6 +113,15 @@ constexpr uint32_t N_XCD = 8;
 #define RT_FIXED_GROUP 8
 #endif
 constexpr uint32_t FIXED_GROUP = RT_FIXED_GROUP;         // consecutive chunks a wave renders in the fixed part of a pass
+// ... and that it takes at once in the part handed out as waves become free: the samples of a tile that follow each other
+// in a run then go to one wave and not to whichever waves ask next, so the chunk that takes up parked probes is of the
+// tile that parked them and the tile's triangles stay in this CU's caches.  Measured (1 / 2 / 4 / 6 / 8 / 16): 424 triangles
+// 15 130-15 310 / - / 15 350 / 15 370 / 15 370 / 15 470, 12 030 triangles 14 720 / 14 900 / 14 910 / 14 920 / 14 890 / 14 700 (large
+// groups leave the waves' regions unevenly filled for the stages that follow), 1 M triangles 7350 / - / 7390 / - / 7320 / -.
+#ifndef RT_DYNAMIC_GROUP
+#define RT_DYNAMIC_GROUP 4
+#endif
+constexpr uint32_t DYNAMIC_GROUP = RT_DYNAMIC_GROUP;
 constexpr uint32_t RUNS_PER_XCD = RT_RUNS_PER_XCD, N_RUNS = N_XCD * RUNS_PER_XCD;
 constexpr uint32_t CHUNK_BLOCK = RT_CHUNK_BLOCK;        // consecutive chunks that stay in one run
 // 1/share of the rounds of the depth-0 kernel is handed out as waves become free (PipeBuffers::dynamic_share): a third
@@ -1037,13 +1046,16 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
         run_x = run_of_part(home, part);
         run_count = n_blocks > run_x ? ((n_blocks - run_x + N_RUNS - 1u) / N_RUNS) * CHUNK_BLOCK : 0u;
     };
-    auto take = [&]() -> uint32_t {
+    // (`n` consecutive chunks of the run with one operation: samples of one tile, rendered by this wave one after the other,
+    // so that what the first fetched the others find in this CU's L1, see DYNAMIC_GROUP)
+    auto take = [&](uint32_t n) -> uint32_t {
         uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(&b.work[run_x], 1u);
+        if (lane == 0) c = atomicAdd(&b.work[run_x], n);
         return c;
     };
     // a run that is used up is seen with a plain read; only a run that has chunks left costs an atomic operation
     auto used_up = [&]() -> bool { return __builtin_nontemporal_load(&b.work[run_x]) >= run_count; };
+    uint32_t grp_next = 0, grp_left = 0, ahead_n = 0;       // the rest of the group this wave has claimed; chunks of the claim under way
     enter_part();
     for (;;) {
         uint32_t chunk;
@@ -1053,26 +1065,40 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
             round++;
         } else {
             uint32_t c;
-            if (have_ahead) {
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
+            if (grp_left != 0u) {
+                c = grp_next++;
+                grp_left--;
+                if (c >= run_count) { grp_left = 0u; continue; }       // the run ended inside the group
             } else {
-                if (used_up()) {
+                uint32_t n;
+                if (have_ahead) {
+                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ahead);
+                    n = ahead_n;
+                } else {
+                    if (used_up()) {
+                        if (++part == N_RUNS) break;
+                        enter_part();
+                        continue;
+                    }
+                    const uint32_t held = fill_next + q_shadow + q_glossy;
+                    if (held + 64u > b.region_cap) { stalled = true; break; }        // this wave's regions cannot take another chunk whole
+                    // a whole group if the regions hold it whatever survives, else one chunk (so that a wave still gets as far
+                    // in a round as the sizing of the regions promises)
+                    n = held + 64u * DYNAMIC_GROUP <= b.region_cap ? DYNAMIC_GROUP : 1u;
+                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)take(n));
+                }
+                have_ahead = false;
+                if (c >= run_count) {
                     if (++part == N_RUNS) break;
                     enter_part();
                     continue;
                 }
-                if (fill_next + q_shadow + q_glossy + 64u > b.region_cap) { stalled = true; break; }        // this wave's regions cannot take another chunk whole
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)take());
+                grp_next = c + 1u;
+                grp_left = n - 1u;
+                // the next group is asked for now if the regions hold this one and the next whatever survives
+                have_ahead = fill_next + q_shadow + q_glossy + 64u * (n + DYNAMIC_GROUP) <= b.region_cap;
+                if (have_ahead) { ahead = take(DYNAMIC_GROUP); ahead_n = DYNAMIC_GROUP; }
             }
-            have_ahead = false;
-            if (c >= run_count) {
-                if (++part == N_RUNS) break;
-                enter_part();
-                continue;
-            }
-            // the next one is asked for now if the region holds this chunk and the next whatever survives
-            have_ahead = fill_next + q_shadow + q_glossy + 128u <= b.region_cap;
-            if (have_ahead) ahead = take();
             const uint32_t block_in_run = c / CHUNK_BLOCK;
             chunk = fixed_chunks + (block_in_run * N_RUNS + run_x) * CHUNK_BLOCK + (c - block_in_run * CHUNK_BLOCK);
         }
