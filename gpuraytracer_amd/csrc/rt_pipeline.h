@@ -117,7 +117,9 @@ constexpr uint32_t FIXED_GROUP = RT_FIXED_GROUP;         // consecutive chunks a
 // in a run then go to one wave and not to whichever waves ask next, so the chunk that takes up parked probes is of the
 // tile that parked them and the tile's triangles stay in this CU's caches.  Measured (1 / 2 / 4 / 6 / 8 / 16): 424 triangles
 // 15 130-15 310 / - / 15 350 / 15 370 / 15 370 / 15 470, 12 030 triangles 14 720 / 14 900 / 14 910 / 14 920 / 14 890 / 14 700 (large
-// groups leave the waves' regions unevenly filled for the stages that follow), 1 M triangles 7350 / - / 7390 / - / 7320 / -.
+// groups leave the waves' regions unevenly filled for the stages that follow), 1 M triangles 7350 / - / 7390 / - / 7320 / -:
+// no gain there, and the depth-0 kernel fetches 1.9 times as much from beyond the L2 (the samples of a tile no longer run
+// on the XCD's compute units at the same time), so scenes from LARGE_SCENE_TRIANGLES on keep single chunks.
 #ifndef RT_DYNAMIC_GROUP
 #define RT_DYNAMIC_GROUP 4
 #endif
@@ -421,6 +423,7 @@ struct PipeBuffers {
     uint32_t round, rounds;                     // round of the pass these launches belong to, and how many it has (see MAX_ROUNDS)
     uint32_t defer_below;                       // a probe search of the depth-0 kernel wants this many lanes, else the chunk parks its probes; 0: never
     uint32_t dynamic_share;                     // 1/dynamic_share of the depth-0 kernel's rounds is handed out as waves become free
+    uint32_t dynamic_group;                     // ... in groups of so many consecutive chunks per wave (DYNAMIC_GROUP)
     unsigned long long *wstats;                 // [PIPE_WAVES][WSTAT_SLOTS] per-wave work counters (see WSTAT_*)
 };
 
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
                     if (held + 64u > b.region_cap) { stalled = true; break; }        // this wave's regions cannot take another chunk whole
                     // a whole group if the regions hold it whatever survives, else one chunk (so that a wave still gets as far
                     // in a round as the sizing of the regions promises)
-                    n = held + 64u * DYNAMIC_GROUP <= b.region_cap ? DYNAMIC_GROUP : 1u;
+                    n = held + 64u * b.dynamic_group <= b.region_cap ? b.dynamic_group : 1u;
                     c = (uint32_t)__builtin_amdgcn_readfirstlane((int)take(n));
                 }
                 have_ahead = false;
@@ -1096,8 +1099,8 @@ __global__ __launch_bounds__(64 * WG_WAVES, CFG::SHARE ? RT_MIN_WAVES : 1) void 
                 grp_next = c + 1u;
                 grp_left = n - 1u;
                 // the next group is asked for now if the regions hold this one and the next whatever survives
-                have_ahead = fill_next + q_shadow + q_glossy + 64u * (n + DYNAMIC_GROUP) <= b.region_cap;
-                if (have_ahead) { ahead = take(DYNAMIC_GROUP); ahead_n = DYNAMIC_GROUP; }
+                have_ahead = fill_next + q_shadow + q_glossy + 64u * (n + b.dynamic_group) <= b.region_cap;
+                if (have_ahead) { ahead = take(b.dynamic_group); ahead_n = b.dynamic_group; }
             }
             const uint32_t block_in_run = c / CHUNK_BLOCK;
             chunk = fixed_chunks + (block_in_run * N_RUNS + run_x) * CHUNK_BLOCK + (c - block_in_run * CHUNK_BLOCK);
@@ -1936,6 +1939,7 @@ inline hipError_t Pipeline::launch_pass(const DScene &sc, const DBvh &bvh, const
         buf.rounds = rounds;
         buf.defer_below = (CFG::BVH && sc.count < DEFER_MAX_TRIANGLES) ? DEFER_BELOW : 0u;
         buf.dynamic_share = (CFG::BVH && sc.count >= LARGE_SCENE_TRIANGLES) ? DYNAMIC_SHARE_LARGE : DYNAMIC_SHARE;
+        buf.dynamic_group = (CFG::BVH && sc.count >= LARGE_SCENE_TRIANGLES) ? 1u : DYNAMIC_GROUP;
         PIPE_TRY(stamp(round == 0 ? 3 : 4));
         if (round == 0) hipLaunchKernelGGL((k_first<CFG, false>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth, form.lists);
         else hipLaunchKernelGGL((k_first<CFG, true>), grid, block, 0, stream, sc, bvh, light_bvh, fr, buf, tab, pps, max_depth, form.lists);
